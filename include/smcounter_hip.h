@@ -1,0 +1,185 @@
+/*
+ * smcounter_hip.h - C ABI of the MI355X (gfx950) implementation of smCounter's per-locus
+ * variant-calling hot path.
+ *
+ * What this replaces in the reference (/root/reference/smCounter.py):
+ *   - vc()            smCounter.py:274-600   one call per locus inside a multiprocessing worker
+ *   - calProb()       smCounter.py:26-98     per-barcode posterior
+ *   - filterVariants  smCounter.py:182-269   FILTER flags (all but the two that read the FASTA)
+ *   - the Pool dispatch of main()  smCounter.py:683-685  (one apply_async per locus) becomes one
+ *     smc_plan_run() over a structure-of-arrays batch of loci.
+ * The reference has no FFI of its own (it is pure Python); the binding a maintainer would add is
+ * the ctypes stub shown in INTEGRATION.md.
+ *
+ * Conventions: plain C, caller owns every buffer, no exceptions cross the boundary; every entry
+ * point returns 0 on success or a negative SMC_E_* code, and smc_last_error() returns the
+ * message of the last failure on the calling thread.  One host thread per GPU.
+ */
+#ifndef SMCOUNTER_HIP_H
+#define SMCOUNTER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMC_ABI_VERSION 1
+#define SMC_MAX_ALLELES 64 /* allele ids per locus; ids 0-5 are A,T,G,C,N,'DEL' */
+
+/* error codes */
+#define SMC_OK 0
+#define SMC_E_ARG (-1)     /* bad argument */
+#define SMC_E_HIP (-2)     /* HIP runtime failure (message has the hipError string) */
+#define SMC_E_NOGPU (-3)   /* no usable gfx950 device */
+#define SMC_E_INPUT (-4)   /* batch violates the layout contract */
+
+/* row.status */
+#define SMC_ST_OK 0
+#define SMC_ST_ZERO_COVERAGE 1      /* usedMT == 0: the 45-field Zero_Coverage row, smCounter.py:492-494 */
+#define SMC_ST_DOWNSAMPLED 0x100    /* more barcodes than ds: reference would random.sample (:496-498) */
+#define SMC_ST_BAD_INPUT 0x200      /* an id in the batch was out of the range its descriptor declares */
+
+/* FILTER bits in smc_cand.flt, in the order filterVariants appends them (smCounter.py:187-266) */
+#define SMC_F_LM 0x001
+#define SMC_F_LSM 0x002
+#define SMC_F_HP 0x004   /* set by the host: needs the reference sequence (smCounter.py:195-199) */
+#define SMC_F_LOWC 0x008 /* set by the host (smCounter.py:202-203) */
+#define SMC_F_DP 0x010
+#define SMC_F_SB 0x020
+#define SMC_F_LOWQ 0x040
+#define SMC_F_R1CP 0x080
+#define SMC_F_R2CP 0x100
+#define SMC_F_PRIMERCP 0x200
+
+/* per-read flag bits inside meta (bits 16-23); see smcounter_amd/features.py */
+#define SMC_FL_R2 1
+#define SMC_FL_REV 2
+#define SMC_FL_MMOK 4
+#define SMC_KIND_SHIFT 3
+#define SMC_KIND_BASE 0
+#define SMC_KIND_GAP 1      /* 'DEL': inside a deletion, quality forced to minBQ (smCounter.py:416-418) */
+#define SMC_KIND_INS 2
+#define SMC_KIND_DELSTART 3
+
+/* The numeric arguments vc() receives (smCounter.py:274) that the device path needs, plus the two
+ * values vc() derives before the pileup loop. mismatchThr and hpLen are consumed on the host
+ * (feature extraction / reference-sequence test). */
+typedef struct smc_params {
+    int32_t min_bq;      /* minBQ */
+    int32_t min_mq;      /* minMQ */
+    int32_t mt_drop;     /* mtDrop */
+    int32_t primer_dist; /* primerDist */
+    int32_t ds;          /* maxMT if > 0 else int(round(2.0 * mtDepth))   smCounter.py:486 */
+    int32_t reserved;
+    double smt;          /* strong-MT threshold 2.0 / 3.0 / 4.0 by rpb    smCounter.py:302-308 */
+} smc_params;
+
+/* One per locus, 32 bytes. Reads of locus l occupy plane slots [read_off, read_off + n_reads);
+ * read_off is a multiple of 4. umi ids are < n_umi; for each umi, frag ids are dense from 0 and
+ * n_frag is the sum over umis of (max frag id + 1) (= allFrag, smCounter.py:483). */
+typedef struct smc_locus {
+    int64_t read_off;
+    int32_t n_reads;
+    int32_t n_umi;
+    int32_t n_frag;
+    uint8_t ref_allele; /* allele id of the reference base, 255 if it is not a key */
+    uint8_t n_alleles;  /* size of the locus's allele table, <= SMC_MAX_ALLELES */
+    uint16_t flags;
+    uint64_t snp_mask;  /* bit a set: allele a is a single letter (TYPE 'SNP', smCounter.py:107) */
+} smc_locus;
+
+/* per-allele tallies of the pileup scan; index names follow the reference's dicts */
+enum {
+    SMC_T_CNT = 0,   /* alleleCnt        smCounter.py:379,401,459 */
+    SMC_T_FWD,       /* forwardCnt       :389,411,457 */
+    SMC_T_REV,       /* reverseCnt       :387,409,455 */
+    SMC_T_LOWQ,      /* lowQReads        :428-429 */
+    SMC_T_R1N,       /* len(r1BcEndPos)  :438-439 */
+    SMC_T_R1LE,      /* #r1BcEndPos <= 20          :234 */
+    SMC_T_R2N,       /* len(r2BcEndPos)  :449-451 */
+    SMC_T_R2BCLE,    /* #r2BcEndPos <= 20          :244 */
+    SMC_T_R2PRLE,    /* #r2PrimerEndPos <= primerDist  :256 */
+    SMC_T_CONCORD,   /* concordPairCnt   :475-476 */
+    SMC_T_DISCORD,   /* discordPairCnt   :479 */
+    SMC_T_PAD,
+    SMC_NT = 12
+};
+
+typedef struct smc_cand {
+    int32_t allele;      /* allele id, -1 when the candidate does not exist */
+    int32_t flt_applied; /* 1 if filterVariants ran (PI >= 5 and TYPE in SNP/INDEL, :549/:563) */
+    uint32_t flt;        /* SMC_F_* bits decided on the device */
+    int32_t vmf_lt_099;  /* 1.0*MTCnt/usedMT < 0.99, the gate of HP and LowC (:198,:202) */
+    int32_t vdp;         /* alleleCnt[allele] */
+    int32_t vmt;         /* MTCnt[allele] */
+    int32_t vsm;         /* strongMTCnt[allele] */
+    int32_t pad;
+    int32_t tal[SMC_NT]; /* tallies of this allele */
+    double pi;           /* finalDict[allele], unrounded */
+    double p_sb, p_r1, p_r2, p_pr; /* Fisher two-sided p-values of the four tests, NaN if not run */
+} smc_cand;
+
+/* One per locus: everything the 45-column row (smCounter.py:575-600) is printed from. 432 bytes. */
+typedef struct smc_row {
+    int32_t status;
+    int32_t n_touched;   /* number of keys in finalDict */
+    int32_t cvg, all_frag, all_mt, used_frag, used_mt; /* DP FR MT UFR UMT */
+    int32_t mt3, mt5, mt7, mt10;
+    int32_t max_allele, second_allele; /* maxBase / secondMaxBase (:535-537) */
+    int32_t biallelic;   /* condition of :555 */
+    int32_t dp[4], umt[4], vsm[4]; /* A,T,G,C: alleleCnt, MTCnt, strongMTCnt */
+    double pi[4];        /* A,T,G,C: finalDict, unrounded */
+    uint64_t touched_mask;
+    int32_t ref_tal[SMC_NT];
+    smc_cand cand[2];    /* [0] origAlt (:541), [1] secondMaxBase when biallelic */
+} smc_row;
+
+typedef struct smc_ctx smc_ctx;
+typedef struct smc_plan smc_plan;
+
+int smc_abi_version(void);
+const char* smc_last_error(void);
+int smc_row_size(void);   /* sizeof(smc_row), for binding self-checks */
+int smc_locus_size(void); /* sizeof(smc_locus) */
+
+/* Number of gfx950 devices visible; does not initialise any of them. */
+int smc_device_count(void);
+
+/* Bind a context to one device (one per process / host thread). */
+int smc_create(int device, smc_ctx** out);
+void smc_destroy(smc_ctx* ctx);
+
+/* Build a launch plan for a batch: bins loci by on-chip table size, uploads the descriptors and the
+ * bin index lists. `loci` is host memory; it is copied. Replaces the construction of the
+ * apply_async task list, smCounter.py:684. */
+int smc_plan_create(smc_ctx* ctx, const smc_locus* loci, int64_t n_loci, smc_plan** out);
+void smc_plan_destroy(smc_plan* plan);
+/* number of kernel launches one smc_plan_run issues, and bytes of device scratch it holds */
+int smc_plan_info(const smc_plan* plan, int32_t* n_launches, int64_t* scratch_bytes);
+
+/* Run the hot path over the batch. meta/umi/frag/dist and rows are DEVICE pointers
+ * (n_slots x uint32 each; rows n_loci x smc_row). `stream` is a hipStream_t (NULL = default
+ * stream). Asynchronous: returns after enqueueing. */
+int smc_plan_run(smc_plan* plan, const smc_params* params, const uint32_t* meta,
+                 const uint32_t* umi, const uint32_t* frag, const uint32_t* dist, smc_row* rows,
+                 void* stream);
+
+/* Convenience for callers without their own device buffers: host pointers in, host rows out
+ * (synchronous; does H2D, smc_plan_run, D2H). */
+int smc_call_batch_host(smc_ctx* ctx, const smc_params* params, const smc_locus* loci,
+                        int64_t n_loci, const uint32_t* meta, const uint32_t* umi,
+                        const uint32_t* frag, const uint32_t* dist, int64_t n_slots,
+                        smc_row* rows_out);
+
+/* HIP-event timing helpers so a host language without HIP bindings can time the stream the
+ * kernels run on. */
+int smc_event_create(void** ev);
+int smc_event_record(void* ev, void* stream);
+int smc_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
+void smc_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMCOUNTER_HIP_H */

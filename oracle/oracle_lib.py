@@ -1,0 +1,53 @@
+"""ctypes loader for oracle/libsmc_oracle.so (the C restatement).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg - never by the product."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(HERE, "libsmc_oracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = ctypes.CDLL(path)
+        _LIB.smc_oracle_call_batch.restype = ctypes.c_int
+        _LIB.smc_oracle_fisher.restype = None
+    return _LIB
+
+
+def call_batch(db, cparams, row_dtype):
+    """db: smcounter_amd.features.DeviceBatch; cparams: ctypes smc_params; -> structured rows."""
+    L = lib()
+    assert L.smc_oracle_row_size() == row_dtype.itemsize
+    rows = np.zeros(db.n_loci, row_dtype)
+    loci = np.ascontiguousarray(db.loci)
+    rc = L.smc_oracle_call_batch(ctypes.byref(cparams), loci.ctypes.data_as(ctypes.c_void_p),
+                                 ctypes.c_int64(db.n_loci),
+                                 db.meta.ctypes.data_as(ctypes.c_void_p),
+                                 db.umi.ctypes.data_as(ctypes.c_void_p),
+                                 db.frag.ctypes.data_as(ctypes.c_void_p),
+                                 db.dist.ctypes.data_as(ctypes.c_void_p),
+                                 rows.ctypes.data_as(ctypes.c_void_p))
+    if rc != 0:
+        raise RuntimeError("smc_oracle_call_batch failed: %d" % rc)
+    return rows
+
+
+def fisher(a, b, c, d):
+    o, p = ctypes.c_double(), ctypes.c_double()
+    lib().smc_oracle_fisher(ctypes.c_int64(a), ctypes.c_int64(b), ctypes.c_int64(c), ctypes.c_int64(d),
+                            ctypes.byref(o), ctypes.byref(p))
+    return o.value, p.value

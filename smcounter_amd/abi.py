@@ -1,0 +1,85 @@
+"""Python mirror of include/smcounter_hip.h: ctypes structs and numpy record dtypes."""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from .params import VcParams
+
+SMC_NT = 12
+(T_CNT, T_FWD, T_REV, T_LOWQ, T_R1N, T_R1LE, T_R2N, T_R2BCLE, T_R2PRLE, T_CONCORD, T_DISCORD,
+ T_PAD) = range(SMC_NT)
+
+ST_OK, ST_ZERO_COVERAGE, ST_DOWNSAMPLED, ST_BAD_INPUT = 0, 1, 0x100, 0x200
+
+F_LM, F_LSM, F_HP, F_LOWC, F_DP, F_SB, F_LOWQ, F_R1CP, F_R2CP, F_PRIMERCP = (
+    1, 2, 4, 8, 16, 32, 64, 128, 256, 512)
+# FILTER names in the order filterVariants appends them (smCounter.py:187-266)
+FILTER_NAMES = ((F_LM, "LM"), (F_LSM, "LSM"), (F_HP, "HP"), (F_LOWC, "LowC"), (F_DP, "DP"),
+                (F_SB, "SB"), (F_LOWQ, "LowQ"), (F_R1CP, "R1CP"), (F_R2CP, "R2CP"),
+                (F_PRIMERCP, "PrimerCP"))
+
+
+class SmcParams(ctypes.Structure):
+    _fields_ = [("min_bq", ctypes.c_int32), ("min_mq", ctypes.c_int32),
+                ("mt_drop", ctypes.c_int32), ("primer_dist", ctypes.c_int32),
+                ("ds", ctypes.c_int32), ("reserved", ctypes.c_int32), ("smt", ctypes.c_double)]
+
+
+def c_params(p: VcParams) -> SmcParams:
+    return SmcParams(p.minBQ, p.minMQ, p.mtDrop, p.primerDist, p.ds, 0, p.smt)
+
+
+CAND_DTYPE = np.dtype([
+    ("allele", "<i4"), ("flt_applied", "<i4"), ("flt", "<u4"), ("vmf_lt_099", "<i4"),
+    ("vdp", "<i4"), ("vmt", "<i4"), ("vsm", "<i4"), ("pad", "<i4"),
+    ("tal", "<i4", (SMC_NT,)), ("pi", "<f8"),
+    ("p_sb", "<f8"), ("p_r1", "<f8"), ("p_r2", "<f8"), ("p_pr", "<f8")])
+assert CAND_DTYPE.itemsize == 120
+
+ROW_DTYPE = np.dtype([
+    ("status", "<i4"), ("n_touched", "<i4"),
+    ("cvg", "<i4"), ("all_frag", "<i4"), ("all_mt", "<i4"), ("used_frag", "<i4"), ("used_mt", "<i4"),
+    ("mt3", "<i4"), ("mt5", "<i4"), ("mt7", "<i4"), ("mt10", "<i4"),
+    ("max_allele", "<i4"), ("second_allele", "<i4"), ("biallelic", "<i4"),
+    ("dp", "<i4", (4,)), ("umt", "<i4", (4,)), ("vsm", "<i4", (4,)),
+    ("pi", "<f8", (4,)), ("touched_mask", "<u8"),
+    ("ref_tal", "<i4", (SMC_NT,)), ("cand", CAND_DTYPE, (2,))])
+assert ROW_DTYPE.itemsize == 432
+
+INT_FIELDS = ("status", "n_touched", "cvg", "all_frag", "all_mt", "used_frag", "used_mt", "mt3", "mt5",
+              "mt7", "mt10", "max_allele", "second_allele", "biallelic", "dp", "umt", "vsm",
+              "touched_mask", "ref_tal")
+CAND_INT_FIELDS = ("allele", "flt_applied", "flt", "vmf_lt_099", "vdp", "vmt", "vsm", "tal")
+CAND_F64_FIELDS = ("pi", "p_sb", "p_r1", "p_r2", "p_pr")
+
+
+def compare_rows(a: np.ndarray, b: np.ndarray, pi_tol=1e-6, p_tol=1e-6):
+    """Field-wise comparison of two row arrays: integer fields bit-exact, PI and Fisher p-values
+    within tolerance.  Returns a list of human-readable mismatches (empty = equal)."""
+    bad = []
+    assert a.shape == b.shape
+    for f in INT_FIELDS:
+        ne = np.nonzero((a[f] != b[f]).reshape(len(a), -1).any(axis=1))[0]
+        for i in ne[:5]:
+            bad.append("locus %d: %s %r != %r" % (i, f, a[f][i].tolist(), b[f][i].tolist()))
+    ok = (a["status"] & 0xff) == ST_OK
+    d = np.abs(a["pi"] - b["pi"])[ok]
+    if d.size and d.max() > pi_tol:
+        bad.append("pi max-abs-diff %g > %g" % (d.max(), pi_tol))
+    for f in CAND_INT_FIELDS:
+        ne = np.nonzero((a["cand"][f] != b["cand"][f]).reshape(len(a), -1).any(axis=1))[0]
+        for i in ne[:5]:
+            bad.append("locus %d: cand.%s %r != %r" % (i, f, a["cand"][f][i].tolist(),
+                                                        b["cand"][f][i].tolist()))
+    for f in CAND_F64_FIELDS:
+        x, y = a["cand"][f], b["cand"][f]
+        nan_mismatch = np.isnan(x) != np.isnan(y)
+        if nan_mismatch.any():
+            bad.append("cand.%s NaN pattern differs at loci %r" % (f, np.nonzero(nan_mismatch.any(axis=1))[0][:5].tolist()))
+        tol = pi_tol if f == "pi" else p_tol
+        dd = np.abs(np.where(np.isnan(x) | np.isnan(y), 0.0, x - y))
+        if dd.size and dd.max() > tol:
+            bad.append("cand.%s max-abs-diff %g > %g" % (f, dd.max(), tol))
+    return bad

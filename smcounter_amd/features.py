@@ -1,0 +1,180 @@
+"""Per-read feature extraction (reference: smCounter.py:327-366, :371-452) and the HBM layout.
+
+Turns a `PileupBatch` into the structure-of-arrays batch the HIP kernels consume: four 32-bit
+planes, 16 bytes per pileup read, every locus's reads contiguous and starting on a 4-read
+(16-byte) boundary so a wavefront reads 1 KiB per plane per load:
+
+    meta[i] = allele | bq << 8 | flags << 16 | mq << 24
+    umi[i]  = barcode index within the locus
+    frag[i] = fragment index within the barcode
+    dist[i] = distToBcEnd | distToPrimerEnd << 16        (regular bases only, saturated)
+
+flags: bit0 pairOrder is R2 (smCounter.py:359-362, carried over from the previous read when a
+record has neither flag, exactly as the reference's un-reset variable does), bit1 reverse strand
+(:365), bit2 `mismatchPer100b <= mismatchThr` (:352-356 and the third term of incCond at
+:378/:400/:421/:431), bits3-4 kind: 0 regular base, 1 'DEL' (inside a deletion, :416),
+2 insertion start (:371), 3 deletion start (:392).
+
+Plus one 32-byte descriptor per locus (`LOCUS_DTYPE`) with the CSR offset, the counts that size
+the on-chip tables (reads, barcodes, fragments) and the allele-table facts the kernels need
+(reference allele id, number of alleles, which alleles are single letters).
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import List
+
+import numpy as np
+
+from .params import VcParams
+from .pileup import (F_READ1, F_READ2, F_REVERSE, MAX_ALLELES, PileupBatch, BASE_ALLELES)
+
+LOCUS_DTYPE = np.dtype([("read_off", "<i8"), ("n_reads", "<i4"), ("n_umi", "<i4"),
+                        ("n_frag", "<i4"), ("ref_allele", "u1"), ("n_alleles", "u1"),
+                        ("flags", "<u2"), ("snp_mask", "<u8")])
+assert LOCUS_DTYPE.itemsize == 32
+
+FL_R2, FL_REV, FL_MMOK = 1, 2, 4
+KIND_SHIFT = 3
+KIND_BASE, KIND_INDEL_GAP, KIND_INS, KIND_DELSTART = 0, 1, 2, 3
+READ_ALIGN = 4
+
+
+class PileupError(Exception):
+    """A record the reference itself would fail on (it would raise inside vc())."""
+
+
+@dataclasses.dataclass
+class DeviceBatch:
+    """Host-side image of the HBM batch (numpy); `engine` uploads it verbatim."""
+    loci: np.ndarray          # LOCUS_DTYPE[n_loci]
+    meta: np.ndarray          # uint32[n_slots]
+    umi: np.ndarray
+    frag: np.ndarray
+    dist: np.ndarray
+    # host-only context for formatting rows
+    chrom: List[str]
+    pos: np.ndarray
+    ref: List[str]
+    alleles: List[List[str]]
+
+    @property
+    def n_loci(self) -> int:
+        return len(self.loci)
+
+    @property
+    def n_slots(self) -> int:
+        return len(self.meta)
+
+    @property
+    def n_reads(self) -> int:
+        return int(self.loci["n_reads"].sum())
+
+    def input_bytes(self) -> int:
+        return 16 * self.n_slots + self.loci.nbytes
+
+
+def ref_allele_id(ref: str, table: List[str]) -> int:
+    try:
+        return table.index(ref)
+    except ValueError:
+        return 255          # reference letter never seen as an allele key
+
+
+def extract_features(pb: PileupBatch, params: VcParams) -> DeviceBatch:
+    n_loci = pb.n_loci
+    n = pb.n_reads
+    lens = np.diff(pb.read_off).astype(np.int64)
+    locus_of = np.repeat(np.arange(n_loci, dtype=np.int64), lens)
+
+    # --- pairOrder: R2 wins over R1; neither -> previous read's value (smCounter.py:359-362)
+    has1 = (pb.flag & F_READ1) != 0
+    has2 = (pb.flag & F_READ2) != 0
+    known = has1 | has2
+    if n:
+        first = pb.read_off[:-1][lens > 0]
+        if not known[first].all():
+            bad = int(locus_of[first[~known[first]][0]])
+            raise PileupError("first pileup read at %s:%d has neither read1 nor read2 set; the "
+                              "reference's pairOrder is undefined there (smCounter.py:359-381)"
+                              % (pb.chrom[bad], pb.pos[bad]))
+        idx = np.where(known, np.arange(n), 0)
+        np.maximum.accumulate(idx, out=idx)
+        is_r2 = has2[idx]
+    else:
+        is_r2 = np.zeros(0, bool)
+    rev = (pb.flag & F_REVERSE) != 0
+
+    # --- mismatches per 100 bases (smCounter.py:352-356), compared with <= (:378)
+    mismatch = np.maximum(0, pb.nm.astype(np.int64) - pb.n_indel.astype(np.int64))
+    qlen = pb.qlen.astype(np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        mm100 = np.where(pb.qlen > 0, 100.0 * mismatch / qlen, 0.0)
+    mm_ok = mm100 <= params.mismatchThr
+
+    # --- allele kind (smCounter.py:371, :392, :416)
+    kind = np.where(pb.indel > 0, KIND_INS,
+                    np.where(pb.indel < 0, KIND_DELSTART,
+                             np.where(pb.is_del, KIND_INDEL_GAP, KIND_BASE))).astype(np.uint32)
+
+    # --- end distances, regular bases only (smCounter.py:432-452)
+    rel = pb.qpos.astype(np.int64) - pb.left_sp.astype(np.int64)
+    far = pb.qalen.astype(np.int64) - rel
+    d_bc = np.where(is_r2, np.where(rev, rel, far), np.where(rev, far, rel))
+    d_pr = np.where(is_r2, np.where(rev, far, rel), 0)
+    regular = kind == KIND_BASE
+    d_bc = np.where(regular, np.clip(d_bc, 0, 65535), 0).astype(np.uint32)
+    d_pr = np.where(regular, np.clip(d_pr, 0, 65535), 0).astype(np.uint32)
+
+    flags = (is_r2.astype(np.uint32) * FL_R2 | rev.astype(np.uint32) * FL_REV
+             | mm_ok.astype(np.uint32) * FL_MMOK | kind << KIND_SHIFT)
+    bq = pb.bq.astype(np.uint32)
+    meta = pb.allele.astype(np.uint32) | bq << 8 | flags << 16 | pb.mq.astype(np.uint32) << 24
+    dist = d_bc | d_pr << 16
+
+    # --- per-locus counts: barcodes, fragments (allMT / allFrag, smCounter.py:482-483)
+    loci = np.zeros(n_loci, LOCUS_DTYPE)
+    n_umi = np.zeros(n_loci, np.int64)
+    n_frag = np.zeros(n_loci, np.int64)
+    if n:
+        np.maximum.at(n_umi, locus_of, pb.umi.astype(np.int64) + 1)
+        ukey = locus_of * (int(n_umi.max()) + 1) + pb.umi.astype(np.int64)
+        uk, inv = np.unique(ukey, return_inverse=True)
+        fmax = np.zeros(len(uk), np.int64)
+        np.maximum.at(fmax, inv, pb.frag.astype(np.int64) + 1)
+        np.add.at(n_frag, uk // (int(n_umi.max()) + 1), fmax)
+
+    # --- padded CSR: each locus starts on a READ_ALIGN boundary
+    padded = (lens + READ_ALIGN - 1) // READ_ALIGN * READ_ALIGN
+    off = np.zeros(n_loci + 1, np.int64)
+    off[1:] = np.cumsum(padded)
+    n_slots = int(off[-1])
+    dst = (off[:-1][locus_of] + (np.arange(n, dtype=np.int64) - pb.read_off[:-1][locus_of])) \
+        if n else np.zeros(0, np.int64)
+
+    def plane(src):
+        out = np.zeros(n_slots, np.uint32)
+        out[dst] = src
+        return out
+
+    loci["read_off"] = off[:-1]
+    loci["n_reads"] = lens
+    loci["n_umi"] = n_umi
+    loci["n_frag"] = n_frag
+    for l in range(n_loci):
+        tab = pb.alleles[l]
+        if len(tab) > MAX_ALLELES:
+            raise PileupError("%s:%d has %d distinct alleles; the device path handles at most %d"
+                              % (pb.chrom[l], pb.pos[l], len(tab), MAX_ALLELES))
+        assert tuple(tab[:6]) == BASE_ALLELES
+        loci["ref_allele"][l] = ref_allele_id(pb.ref[l], tab)
+        loci["n_alleles"][l] = len(tab)
+        mask = 0
+        for a, s in enumerate(tab):
+            if len(s) == 1:
+                mask |= 1 << a
+        loci["snp_mask"][l] = mask
+
+    return DeviceBatch(loci=loci, meta=plane(meta), umi=plane(pb.umi), frag=plane(pb.frag),
+                       dist=plane(dist), chrom=list(pb.chrom), pos=pb.pos.copy(),
+                       ref=list(pb.ref), alleles=[list(t) for t in pb.alleles])

@@ -1,0 +1,235 @@
+"""Seeded synthetic pileups of stated depth (BASELINE.json configs C2-C5).
+
+Per locus: `n_umi` barcodes, each with `rpb` reads arranged as fragments of which a fraction
+`p_overlap` have both mates on the locus (R1 forward + R2 reverse) and the rest a single R1 or
+R2; reads randomly interleaved (coordinate-sort stand-in); barcode / fragment ids relabelled by
+first appearance.  True allele per barcode is the reference base (optionally an alt at a small
+fraction of loci), per-read sequencing error, a sprinkle of in-deletion reads and one insertion
+and one deletion-start allele per locus, base qualities / MAPQ / mismatch counts / read lengths /
+soft clips / query positions drawn from fixed small distributions.
+
+The reference genome is the periodic string whose 1-based position p holds "ACGT"[p % 4]
+(`CyclicRef`), so deletion alleles and reference bases are consistent without a FASTA file.
+"""
+from __future__ import annotations
+
+import dataclasses
+
+import numpy as np
+
+from .pileup import (F_HAS_NM, F_READ1, F_READ2, F_REVERSE, PileupBatch, BASE_ALLELES)
+
+_LETTERS = "ACGT"
+# allele ids are in atgc order: A=0, T=1, G=2, C=3
+_LETTER_TO_ID = {"A": 0, "T": 1, "G": 2, "C": 3}
+_REF_ID_BY_PMOD4 = np.array([_LETTER_TO_ID[c] for c in _LETTERS], np.uint8)   # pos % 4 -> id
+_ID_TO_LETTER = np.array(list("ATGC"))
+
+
+class CyclicRef(object):
+    """Reference provider: base at 1-based position p is "ACGT"[p % 4]."""
+
+    def __init__(self, length=1 << 31):
+        self._len = length
+
+    def get_reference_length(self, chrom):
+        return self._len
+
+    def fetch(self, chrom, start, end):
+        start = max(0, start)
+        end = min(end, self._len)
+        if end <= start:
+            return ""
+        p = np.arange(start + 1, end + 1)
+        return "".join(_LETTERS[i] for i in (p % 4))
+
+
+class StringRef(object):
+    """Reference provider over in-memory chromosome strings."""
+
+    def __init__(self, chroms):
+        self._c = {k: v.upper() for k, v in chroms.items()}
+
+    def get_reference_length(self, chrom):
+        return len(self._c[chrom])
+
+    def fetch(self, chrom, start, end):
+        return self._c[chrom][max(0, start):end]
+
+
+@dataclasses.dataclass(frozen=True)
+class SynthConfig:
+    name: str
+    n_loci: int
+    n_umi: int
+    rpb: int
+    seed: int
+    start_pos: int = 1_000_000
+    chrom: str = "chrS"
+    p_overlap: float = 0.43
+    p_err: float = 1e-3
+    p_gap: float = 2e-3         # read is inside a deletion ('DEL')
+    p_ins: float = 1e-3         # insertion-start allele
+    p_delstart: float = 1e-3    # deletion-start allele
+    alt_locus_frac: float = 0.0
+    alt_af: float = 0.0
+    p_n: float = 2e-4           # base called N
+
+    @property
+    def depth(self) -> int:
+        return self.n_umi * self.rpb
+
+
+CONFIGS = {
+    # BASELINE.json configs[1..4]; seeds 20170410 + config index
+    "C2": SynthConfig("C2", 10_000, 30, 10, 20170412),
+    "C3": SynthConfig("C3", 200_000, 50, 60, 20170413),
+    "C4": SynthConfig("C4", 1_000_000, 50, 60, 20170414),
+    "C5": SynthConfig("C5", 100_000, 133, 60, 20170415, alt_locus_frac=0.01, alt_af=0.005),
+}
+
+
+def params_for(cfg: SynthConfig):
+    from .params import VcParams
+    return VcParams(minBQ=20, minMQ=30, mtDepth=cfg.n_umi, rpb=float(cfg.rpb), hpLen=8,
+                    mismatchThr=6.0, mtDrop=0, maxMT=0, primerDist=2)
+
+
+def generate(cfg: SynthConfig, lo: int = 0, hi: int = None, return_counts: bool = False):
+    """Loci [lo, hi) of the config.  Each locus draws from its own seed sequence child only through
+    the chunk RNG below, so a given (cfg, lo, hi) is reproducible; chunks are independent."""
+    hi = cfg.n_loci if hi is None else hi
+    nl = hi - lo
+    U, B = cfg.n_umi, cfg.rpb
+    R = U * B
+    rng = np.random.Generator(np.random.PCG64([cfg.seed, lo, hi]))
+    pos = cfg.start_pos + np.arange(lo, hi, dtype=np.int64)
+    ref_id = _REF_ID_BY_PMOD4[pos % 4]                                   # (nl,)
+
+    # ---- fragment structure per barcode, original (l, u, j) order
+    f0 = max(1, int(round(B / (1.0 + cfg.p_overlap))))
+    k_pairs = np.minimum(rng.binomial(f0, cfg.p_overlap, size=(nl, U)), B // 2)   # (nl,U)
+    j = np.arange(B)[None, None, :]
+    in_pair = j < 2 * k_pairs[:, :, None]
+    frag_orig = np.where(in_pair, j // 2, j - k_pairs[:, :, None])                  # (nl,U,B)
+    single_r2 = rng.random((nl, U, B)) < 0.5
+    is_r2 = np.where(in_pair, (j % 2) == 1, single_r2)
+    flip = rng.random((nl, U, B)) < 0.1
+    is_rev = is_r2 ^ flip
+
+    # ---- alleles
+    true_id = np.broadcast_to(ref_id[:, None], (nl, U)).copy()
+    if cfg.alt_locus_frac > 0:
+        alt_locus = rng.random(nl) < cfg.alt_locus_frac
+        # fixed transition: A<->G, C<->T  (ids A0 T1 G2 C3)
+        trans = np.array([2, 3, 0, 1], np.uint8)
+        alt_umi = (rng.random((nl, U)) < cfg.alt_af) & alt_locus[:, None]
+        true_id = np.where(alt_umi, trans[true_id], true_id)
+    allele = np.broadcast_to(true_id[:, :, None], (nl, U, B)).copy()
+    err = rng.random((nl, U, B)) < cfg.p_err
+    shift = rng.integers(1, 4, size=(nl, U, B), dtype=np.uint8)
+    allele = np.where(err, (allele + shift) % 4, allele).astype(np.uint8)
+    carries_alt = allele != ref_id[:, None, None]
+    ev = rng.random((nl, U, B))
+    is_gap = ev < cfg.p_gap
+    is_ins = (ev >= cfg.p_gap) & (ev < cfg.p_gap + cfg.p_ins)
+    is_dst = (ev >= cfg.p_gap + cfg.p_ins) & (ev < cfg.p_gap + cfg.p_ins + cfg.p_delstart)
+    is_n = (ev >= 1.0 - cfg.p_n)
+    allele = np.where(is_n, 4, allele)
+    allele = np.where(is_gap, 5, allele)
+    # per-locus table: ids 6 / 7 assigned to whichever of INS / DEL-start occurs (first wins id 6)
+    allele = np.where(is_ins, 254, allele)     # placeholders, fixed after the shuffle
+    allele = np.where(is_dst, 253, allele)
+
+    bq = rng.choice(np.array([12, 25, 30, 37, 40], np.uint8), size=(nl, U, B),
+                    p=[.03, .07, .2, .4, .3])
+    mq = np.where(rng.random((nl, U, B)) < 0.02, 20, 60).astype(np.uint8)
+    mism = rng.choice(np.array([0, 1, 2], np.uint32), size=(nl, U, B), p=[.8, .15, .05])
+    mism = mism + (carries_alt & ~is_gap & ~is_ins & ~is_dst & ~is_n)
+    mism = np.where(rng.random((nl, U, B)) < 0.01, 8, mism).astype(np.uint32)
+    n_indel = (is_gap | is_ins | is_dst).astype(np.uint32)
+    nm = mism + n_indel
+    qlen = rng.integers(100, 151, size=(nl, U, B), dtype=np.uint32)
+    left_sp = np.where(rng.random((nl, U, B)) < 0.05,
+                       rng.integers(1, 11, size=(nl, U, B)), 0).astype(np.uint32)
+    qalen = qlen - left_sp
+    qpos = (left_sp + (rng.random((nl, U, B)) * qalen).astype(np.uint32)).astype(np.int32)
+    indel = np.where(is_ins, 1, np.where(is_dst, -1, 0)).astype(np.int32)
+    flag = (np.where(is_r2, F_READ2, F_READ1) | np.where(is_rev, F_REVERSE, 0)
+            | F_HAS_NM).astype(np.uint8)
+
+    # ---- random interleave within each locus
+    order = rng.permuted(np.broadcast_to(np.arange(R, dtype=np.int32), (nl, R)), axis=1)
+    rows = np.arange(nl)[:, None]
+    newpos = np.empty((nl, R), np.int32)
+    newpos[rows, order] = np.arange(R, dtype=np.int32)[None, :]
+    newpos3 = newpos.reshape(nl, U, B)
+
+    # barcode ids by first appearance
+    first_u = newpos3.min(axis=2)                                      # (nl,U)
+    umi_rank = np.empty((nl, U), np.uint32)
+    umi_rank[rows, np.argsort(first_u, axis=1)] = np.arange(U, dtype=np.uint32)[None, :]
+    # fragment ids within barcode by first appearance
+    n_frag_u = B - k_pairs                                             # (nl,U) fragments per barcode
+    big = np.int32(R + 1)
+    # first position of original fragment f: pairs occupy reads (2f, 2f+1), singles read f + k
+    npad = np.concatenate([newpos3, np.full((nl, U, 1), big, np.int32)], axis=2)
+    f_idx = np.arange(B)[None, None, :]
+    kk = k_pairs[:, :, None]
+    pair_first = np.minimum(np.take_along_axis(npad, np.minimum(2 * f_idx, B), axis=2),
+                            np.take_along_axis(npad, np.minimum(2 * f_idx + 1, B), axis=2))
+    single_first = np.take_along_axis(npad, np.minimum(f_idx + kk, B), axis=2)
+    ffirst = np.where(f_idx < kk, pair_first, single_first)           # (nl,U,B), big when f >= nfrag
+    frank = np.empty((nl, U, B), np.uint32)
+    fo = np.argsort(ffirst, axis=2, kind="stable")
+    np.put_along_axis(frank, fo, np.broadcast_to(np.arange(B, dtype=np.uint32), (nl, U, B)), axis=2)
+    frag_new = np.take_along_axis(frank, frag_orig, axis=2)
+    umi_new = np.broadcast_to(umi_rank[:, :, None], (nl, U, B))
+
+    def shuf(x):
+        return np.take_along_axis(np.ascontiguousarray(x).reshape(nl, R), order, axis=1).reshape(-1)
+
+    allele_s = shuf(allele).reshape(nl, R)
+    # allele table: INS gets the lower id if it appears first, else DEL-start
+    has_ins = (allele_s == 254)
+    has_dst = (allele_s == 253)
+    first_ins = np.where(has_ins.any(axis=1), has_ins.argmax(axis=1), R + 1)
+    first_dst = np.where(has_dst.any(axis=1), has_dst.argmax(axis=1), R + 1)
+    ins_id = np.where(first_ins < first_dst, 6, 7)
+    dst_id = np.where(first_dst < first_ins, 6, np.where(first_ins <= R, 7, 6))
+    allele_s = np.where(has_ins, ins_id[:, None], allele_s)
+    allele_s = np.where(has_dst, dst_id[:, None], allele_s).astype(np.uint8)
+
+    ref_letters = _ID_TO_LETTER[ref_id]
+    alleles = []
+    base = list(BASE_ALLELES)
+    pl = pos.tolist()
+    fi, fd = first_ins.tolist(), first_dst.tolist()
+    for l in range(nl):
+        if fi[l] > R and fd[l] > R:
+            alleles.append(base)
+            continue
+        r = ref_letters[l]
+        p = pl[l]
+        ins_s = "INS|%s|%s%s" % (r, r, _LETTERS[(p + 2) % 4])
+        del_s = "DEL|%s%s|%s" % (r, _LETTERS[(p + 1) % 4], r)
+        extra = []
+        if fi[l] <= R and fd[l] <= R:
+            extra = [ins_s, del_s] if fi[l] < fd[l] else [del_s, ins_s]
+        elif fi[l] <= R:
+            extra = [ins_s]
+        else:
+            extra = [del_s]
+        alleles.append(base + extra)
+
+    read_off = np.arange(nl + 1, dtype=np.int64) * R
+    pb = PileupBatch(
+        chrom=[cfg.chrom] * nl, pos=pos, ref=ref_letters.tolist(), alleles=alleles,
+        read_off=read_off,
+        umi=shuf(umi_new).astype(np.uint32), frag=shuf(frag_new).astype(np.uint32),
+        flag=shuf(flag), mq=shuf(mq), nm=shuf(nm), n_indel=shuf(n_indel), left_sp=shuf(left_sp),
+        qlen=shuf(qlen), qalen=shuf(qalen), qpos=shuf(qpos), indel=shuf(indel),
+        is_del=shuf(is_gap), allele=allele_s.reshape(-1), bq=shuf(bq))
+    if return_counts:
+        return pb, (np.full(nl, U, np.int64), n_frag_u.sum(axis=1).astype(np.int64))
+    return pb
