@@ -44,6 +44,7 @@ class _Capture(object):
         self.round2 = []     # arguments of round(x, 2) in call order -> PI_A, PI_T, PI_G, PI_C, PI_alt
         self.fisher = []     # (table, oddsratio, pvalue)
         self.calprob = []    # per-UMI posterior dicts, in bcKeys order
+        self.final = []      # finalDict.items() as handed to sorted() (smCounter.py:534)
 
 
 CAP = _Capture()
@@ -51,6 +52,7 @@ CAP = _Capture()
 
 def _py2_sorted(iterable, key=None, reverse=False):
     items = list(iterable)
+    CAP.final = [(k, float(v)) for k, v in items] if items and isinstance(items[0], tuple) else []
     if items and all(isinstance(it, tuple) and len(it) == 2 and isinstance(it[0], str)
                      for it in items):
         order = py2compat.py2_dict_order([k for k, _ in items])
@@ -141,6 +143,23 @@ def locus_to_stub_reads(pb, l):
     return out
 
 
+def _tie_ambiguous(final_items):
+    """True when the allele picked at smCounter.py:535-542 hinges on an exact PI tie that involves a
+    key other than A/T/G/C: its order in a py2 dict depends on hash collisions and insertion
+    history that cannot be reproduced, so ALT-dependent columns are not pinned."""
+    if len(final_items) < 2:
+        return False
+    srt = builtins.sorted(final_items, key=lambda kv: -kv[1])
+    groups = []
+    for idx in (0, 1):
+        v = srt[idx][1]
+        groups.append([k for k, x in final_items if x == v])
+    for g in groups:
+        if len(g) > 1 and any(k not in ("A", "T", "G", "C") for k in g):
+            return True
+    return False
+
+
 _MOD = None
 
 
@@ -169,7 +188,7 @@ def run_reference(pb, params, chroms, use_wrapper=True):
                      params.mtDepth, params.rpb, params.hpLen, params.mismatchThr, params.mtDrop,
                      params.maxMT, params.primerDist, fa)
         res.append(dict(row=row, pi_raw=list(CAP.round2), fisher=list(CAP.fisher),
-                        n_umi_used=len(CAP.calprob)))
+                        n_umi_used=len(CAP.calprob), tie_ambiguous=_tie_ambiguous(CAP.final)))
     return res
 
 

@@ -1,0 +1,64 @@
+"""ctypes binding of libsmcounter_hip.so (include/smcounter_hip.h).  Fails loudly: there is no
+CPU fallback in the product path."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+from . import abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsmcounter_hip.so")
+
+SYMBOLS = ("smc_abi_version", "smc_last_error", "smc_row_size", "smc_locus_size", "smc_device_count",
+           "smc_create", "smc_destroy", "smc_plan_create", "smc_plan_destroy", "smc_plan_info",
+           "smc_plan_run", "smc_call_batch_host", "smc_event_create", "smc_event_record",
+           "smc_event_elapsed_ms", "smc_event_destroy")
+
+
+class SmcError(RuntimeError):
+    pass
+
+
+_LIB = None
+
+
+def load():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise SmcError("HIP library missing: %s - run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(or python -m smcounter_amd.build); there is no CPU fallback" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+    L.smc_abi_version.restype = ctypes.c_int
+    L.smc_last_error.restype = ctypes.c_char_p
+    L.smc_row_size.restype = ctypes.c_int
+    L.smc_locus_size.restype = ctypes.c_int
+    L.smc_device_count.restype = ctypes.c_int
+    L.smc_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+    L.smc_destroy.argtypes = [vp]
+    L.smc_destroy.restype = None
+    L.smc_plan_create.argtypes = [vp, vp, i64, ctypes.POINTER(vp)]
+    L.smc_plan_destroy.argtypes = [vp]
+    L.smc_plan_destroy.restype = None
+    L.smc_plan_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i64)]
+    L.smc_plan_run.argtypes = [vp, ctypes.POINTER(abi.SmcParams), vp, vp, vp, vp, vp, vp]
+    L.smc_call_batch_host.argtypes = [vp, ctypes.POINTER(abi.SmcParams), vp, i64, vp, vp, vp, vp, i64, vp]
+    L.smc_event_create.argtypes = [ctypes.POINTER(vp)]
+    L.smc_event_record.argtypes = [vp, vp]
+    L.smc_event_elapsed_ms.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_float)]
+    L.smc_event_destroy.argtypes = [vp]
+    L.smc_event_destroy.restype = None
+    if L.smc_abi_version() != 1:
+        raise SmcError("ABI version mismatch")
+    if L.smc_row_size() != abi.ROW_DTYPE.itemsize or L.smc_locus_size() != 32:
+        raise SmcError("struct layout mismatch between include/smcounter_hip.h and smcounter_amd/abi.py")
+    _LIB = L
+    return L
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise SmcError("%s failed (%d): %s" % (what, rc, load().smc_last_error().decode()))

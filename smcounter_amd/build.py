@@ -1,0 +1,39 @@
+"""Builds the gfx950 shared library in-tree (hipcc cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = os.path.join(HERE, "csrc", "smcounter_hip.hip")
+LIB = os.path.join(HERE, "libsmcounter_hip.so")
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off",
+               "-I" + os.path.join(ROOT, "include")]
+
+
+def hipcc_path() -> str:
+    p = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(p):
+        raise RuntimeError("hipcc not found; the HIP library cannot be built")
+    return p
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [SRC, os.path.join(ROOT, "include", "smcounter_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_hip(force: bool = False, extra_flags=()) -> str:
+    if force or needs_build():
+        cmd = [hipcc_path()] + HIPCC_FLAGS + list(extra_flags) + ["-o", LIB, SRC]
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_hip(force=True))

@@ -1,0 +1,1095 @@
+// smcounter_hip.hip - MI355X (gfx950) kernels and C ABI for smCounter's per-locus hot path.
+//
+// One workgroup per locus.  The whole of vc() up to (not including) string formatting runs on
+// the device (reference: /root/reference/smCounter.py):
+//   scan     per-read inclusion test + per-allele tallies            smCounter.py:368-460
+//   group    barcode -> fragment table in LDS, mate merge             :462-479
+//   score    calProb per barcode, PI / consensus accumulation         :26-98, :506-532
+//   rank     top-2 alleles, candidate(s), bi-allelic pre-condition    :534-555
+//   filter   filterVariants minus the two FASTA-dependent flags       :182-269  (second kernel)
+//
+// Data layout (see include/smcounter_hip.h, smcounter_amd/features.py): four uint32 planes, 16 B
+// per pileup read, reads of a locus contiguous and 16-byte aligned; barcode ids dense per locus,
+// fragment ids dense per barcode, so the on-chip tables are directly indexed (no hashing).
+//
+// On-chip tables per locus (dynamic LDS, or a global scratch slab for loci that do not fit):
+//   umi_base[nU+1]  fragments-per-barcode (atomicMax) then their exclusive prefix sum
+//   umi_flag[nU]    barcode has an included read (= is a key of bcDict)
+//   fmin/fmax[nF]   per fragment: smallest / largest packed key (read index | allele | quality)
+//                   of its included reads; read order matters to the reference (first mate
+//                   defines the base, :468-479) and min/max of the index recovers it without a
+//                   sort for fragments with <= 2 included reads; the rare longer ones are
+//                   replayed sequentially.
+// This is integer/branchy, HBM-streaming work: no MFMA.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "smcounter_hip.h"
+
+#define WAVE 64
+#define N_ID 4
+#define GAP_ID 5
+
+// ------------------------------------------------------------------------------------------
+// device side
+// ------------------------------------------------------------------------------------------
+struct KParams {
+    int min_bq, min_mq, mt_drop, primer_dist, ds;
+    double smt;
+};
+
+// header of the per-block LDS image; the tables follow it
+struct Hdr {
+    uint32_t misc[32];
+    uint32_t scan_tmp[32];
+};
+enum {
+    M_NINC = 0,   // included reads
+    M_RESOLVED,   // reads accounted for by <=2-read fragments
+    M_ERR,
+    M_NBC,        // barcodes with an included read
+    M_ALLMT,
+    M_TOTFRAG,
+    M_MT3, M_MT5, M_MT7, M_MT10,
+    M_USEDFRAG,
+    M_TOUCH_LO, M_TOUCH_HI,
+    M_CVG,
+    M_NEEDFIX,
+};
+
+#define NT_K1 11  // tallies kept per allele in LDS: the SMC_T_* of the header, without the pad
+
+__device__ __forceinline__ uint32_t lds_hdr_bytes(int a_cap) {
+    // Hdr + tal[a_cap][SMC_NT] + pifx[a_cap] (u64) + mtc[a_cap] + strong[a_cap] + row stage
+    return (uint32_t)(sizeof(Hdr) + a_cap * SMC_NT * 4 + a_cap * 8 + a_cap * 4 + a_cap * 4 + sizeof(smc_row));
+}
+
+__device__ __forceinline__ double wave_reduce_mul(double v, int width) {
+    for (int m = 1; m < width; m <<= 1) v *= __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ int wave_reduce_add(int v, int width) {
+    for (int m = 1; m < width; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_reduce_or(uint32_t v, int width) {
+    for (int m = 1; m < width; m <<= 1) v |= __shfl_xor((int)v, m);
+    return v;
+}
+__device__ __forceinline__ long long wave_reduce_add64(long long v, int width) {
+    for (int m = 1; m < width; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+// block-wide exclusive prefix sum over arr[0..n) in place; returns the total (in all threads).
+template <int BLOCK>
+__device__ uint32_t block_exclusive_scan(uint32_t* arr, int n, uint32_t* tmp /*>= 32 u32 in LDS*/) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    constexpr int NW = BLOCK / WAVE;
+    uint32_t carry = 0;
+    for (int base = 0; base < n; base += BLOCK) {
+        int i = base + tid;
+        uint32_t v = i < n ? arr[i] : 0u;
+        uint32_t inc = v;
+        for (int d = 1; d < WAVE; d <<= 1) {
+            uint32_t t = __shfl_up((int)inc, d);
+            if (lane >= d) inc += t;
+        }
+        if (lane == 63) tmp[wid] = inc;
+        __syncthreads();
+        uint32_t woff = 0, tot = 0;
+        for (int w = 0; w < NW; ++w) {
+            uint32_t t = tmp[w];
+            if (w < wid) woff += t;
+            tot += t;
+        }
+        if (i < n) arr[i] = carry + woff + inc - v;
+        carry += tot;
+        __syncthreads();
+    }
+    return carry;
+}
+
+__device__ __forceinline__ uint32_t make_key(int idx, int allele, int bq) {
+    return ((uint32_t)idx << 14) | ((uint32_t)allele << 8) | (uint32_t)bq;
+}
+#define KEY_ALLELE(k) (((k) >> 8) & 63u)
+#define KEY_BQ(k) ((k) & 255u)
+// fragment state word (after resolve), kept in fmin[]
+#define ST_PRESENT 0x80000000u
+#define ST_PAIRED 0x40000000u
+__device__ __forceinline__ uint32_t make_state(int allele, int bq, bool paired) {
+    return ST_PRESENT | (paired ? ST_PAIRED : 0u) | ((uint32_t)allele << 8) | (uint32_t)bq;
+}
+
+struct ReadRec {
+    int allele, bq_eff, kind;
+    bool inc, r2, rev, lowq;
+    int dbc, dpr;
+};
+
+__device__ __forceinline__ ReadRec decode_read(uint32_t m, uint32_t d, const KParams& P) {
+    ReadRec r;
+    r.allele = m & 0xff;
+    int bq = (m >> 8) & 0xff, fl = (m >> 16) & 0xff, mq = m >> 24;
+    r.kind = (fl >> SMC_KIND_SHIFT) & 3;
+    r.r2 = fl & SMC_FL_R2;
+    r.rev = fl & SMC_FL_REV;
+    r.lowq = (r.kind == SMC_KIND_BASE) && bq < P.min_bq;          // smCounter.py:428
+    r.bq_eff = (r.kind == SMC_KIND_GAP) ? P.min_bq : bq;          // :418
+    r.inc = r.bq_eff >= P.min_bq && mq >= P.min_mq && (fl & SMC_FL_MMOK);  // :378
+    r.dbc = d & 0xffff;
+    r.dpr = d >> 16;
+    return r;
+}
+
+// pow(10, x) and log10 in double; the LUT of 10^(-q/10) is computed on the host with the same libm
+// the CPU restatement uses.
+__device__ __forceinline__ double pcr_of(int cnt, double denom) { return pow(10.0, -6.0 * ((cnt + 0.5) / denom)); }
+
+// ------------------------------------------------------------------------------------------
+// kernel 1: scan + group + score + rank
+// ------------------------------------------------------------------------------------------
+template <int BLOCK, bool GLOBAL_TABLES>
+__global__ __launch_bounds__(BLOCK) void k_call_loci(
+    KParams P, const smc_locus* __restrict__ loci, const int* __restrict__ order, int a_cap,
+    const uint32_t* __restrict__ g_meta, const uint32_t* __restrict__ g_umi, const uint32_t* __restrict__ g_frag,
+    const uint32_t* __restrict__ g_dist, const double* __restrict__ lut, smc_row* __restrict__ rows,
+    uint8_t* __restrict__ scratch, const int64_t* __restrict__ scratch_off) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = order[blockIdx.x];
+    const smc_locus L = loci[li];
+    const int n = L.n_reads, nU = L.n_umi, nF = L.n_frag, nA = L.n_alleles;
+    const uint32_t* meta = g_meta + L.read_off;
+    const uint32_t* umi = g_umi + L.read_off;
+    const uint32_t* frag = g_frag + L.read_off;
+    const uint32_t* dist = g_dist + L.read_off;
+
+    // ---- carve LDS
+    Hdr* H = (Hdr*)smem;
+    uint32_t* tal = (uint32_t*)(smem + sizeof(Hdr));                 // [a_cap][SMC_NT]
+    unsigned long long* pifx = (unsigned long long*)(tal + a_cap * SMC_NT);
+    uint32_t* mtc = (uint32_t*)(pifx + a_cap);
+    uint32_t* strong = mtc + a_cap;
+    smc_row* rowst = (smc_row*)(strong + a_cap);
+    unsigned char* tab = GLOBAL_TABLES ? (scratch + scratch_off[blockIdx.x]) : (smem + lds_hdr_bytes(a_cap));
+    uint32_t* umi_base = (uint32_t*)tab;                              // [nU+1]
+    uint32_t* fmin = umi_base + (nU + 1);                             // [nF]
+    uint32_t* fmax = fmin + nF;                                       // [nF]
+    unsigned char* umi_flag = (unsigned char*)(fmax + nF);            // [nU]
+
+    // ---- S0: init
+    {
+        uint32_t* z = (uint32_t*)smem;
+        const int nz = (int)(lds_hdr_bytes(a_cap) / 4);
+        for (int i = tid; i < nz; i += BLOCK) z[i] = 0;
+        for (int i = tid; i <= nU; i += BLOCK) umi_base[i] = 0;
+        for (int i = tid; i < nU; i += BLOCK) umi_flag[i] = 0;
+        for (int i = tid; i < nF; i += BLOCK) { fmin[i] = 0xFFFFFFFFu; fmax[i] = 0u; }
+    }
+    __syncthreads();
+
+    // ---- P1: per-read inclusion test and tallies (smCounter.py:368-460), fragments per barcode
+    // (allBcDict, :463-464), which barcodes enter bcDict (:467-468).
+    {
+        uint32_t acc[4][9];   // wave-uniform (SGPR) tallies of A,T,G,C
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc[a][k] = 0;
+        uint32_t n_inc_w = 0, err_w = 0;
+        for (int base = 0; base < n; base += BLOCK) {
+            const int i = base + tid;
+            const bool valid = i < n;
+            uint32_t m = 0, u = 0, f = 0, d = 0;
+            if (valid) { m = meta[i]; u = umi[i]; f = frag[i]; d = dist[i]; }
+            ReadRec r = decode_read(m, d, P);
+            bool ok = valid && u < (uint32_t)nU && r.allele < nA;
+            if (__ballot(valid && !ok)) err_w = 1;
+            const bool inc = ok && r.inc;
+            const bool regular = r.kind == SMC_KIND_BASE;
+            const bool r1i = inc && regular && !r.r2, r2i = inc && regular && r.r2;
+            const unsigned long long b_fwd = __ballot(ok && r.kind != SMC_KIND_GAP && !r.rev);
+            const unsigned long long b_rev = __ballot(ok && r.kind != SMC_KIND_GAP && r.rev);
+            const unsigned long long b_lowq = __ballot(ok && r.lowq);
+            const unsigned long long b_r1n = __ballot(r1i);
+            const unsigned long long b_r1le = __ballot(r1i && r.dbc <= 20);
+            const unsigned long long b_r2n = __ballot(r2i);
+            const unsigned long long b_r2bc = __ballot(r2i && r.dbc <= 20);
+            const unsigned long long b_r2pr = __ballot(r2i && r.dpr <= P.primer_dist);
+            n_inc_w += __popcll(__ballot(inc));
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const unsigned long long ma = __ballot(ok && r.allele == a);
+                if (ma) {
+                    acc[a][SMC_T_CNT] += __popcll(ma);
+                    acc[a][SMC_T_FWD] += __popcll(ma & b_fwd);
+                    acc[a][SMC_T_REV] += __popcll(ma & b_rev);
+                    acc[a][SMC_T_LOWQ] += __popcll(ma & b_lowq);
+                    acc[a][SMC_T_R1N] += __popcll(ma & b_r1n);
+                    acc[a][SMC_T_R1LE] += __popcll(ma & b_r1le);
+                    acc[a][SMC_T_R2N] += __popcll(ma & b_r2n);
+                    acc[a][SMC_T_R2BCLE] += __popcll(ma & b_r2bc);
+                    acc[a][SMC_T_R2PRLE] += __popcll(ma & b_r2pr);
+                }
+            }
+            if (ok && r.allele >= 4) {   // rare alleles: straight LDS atomics
+                uint32_t* t = tal + r.allele * SMC_NT;
+                atomicAdd(&t[SMC_T_CNT], 1u);
+                if (r.kind != SMC_KIND_GAP) atomicAdd(&t[r.rev ? SMC_T_REV : SMC_T_FWD], 1u);
+                if (r.lowq) atomicAdd(&t[SMC_T_LOWQ], 1u);
+                if (r1i) { atomicAdd(&t[SMC_T_R1N], 1u); if (r.dbc <= 20) atomicAdd(&t[SMC_T_R1LE], 1u); }
+                if (r2i) {
+                    atomicAdd(&t[SMC_T_R2N], 1u);
+                    if (r.dbc <= 20) atomicAdd(&t[SMC_T_R2BCLE], 1u);
+                    if (r.dpr <= P.primer_dist) atomicAdd(&t[SMC_T_R2PRLE], 1u);
+                }
+            }
+            if (ok) {
+                atomicMax(&umi_base[u], f + 1u);
+                if (inc) umi_flag[u] = 1;
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    if (acc[a][k]) atomicAdd(&tal[a * SMC_NT + k], acc[a][k]);
+            if (n_inc_w) atomicAdd(&H->misc[M_NINC], n_inc_w);
+            if (err_w) H->misc[M_ERR] = 1;
+        }
+    }
+    __syncthreads();
+
+    // ---- S2: barcode bookkeeping: allMT, bcDict size, fragment offsets
+    {
+        uint32_t nbc = 0, allmt = 0;
+        for (int u = tid; u < nU; u += BLOCK) { nbc += umi_flag[u]; allmt += umi_base[u] > 0; }
+        nbc = wave_reduce_add((int)nbc, WAVE);
+        allmt = wave_reduce_add((int)allmt, WAVE);
+        if (lane == 0) { atomicAdd(&H->misc[M_NBC], nbc); atomicAdd(&H->misc[M_ALLMT], allmt); }
+    }
+    __syncthreads();
+    {
+        uint32_t tot = block_exclusive_scan<BLOCK>(umi_base, nU, H->scan_tmp);
+        if (tid == 0) { umi_base[nU] = tot; H->misc[M_TOTFRAG] = tot; if (tot != (uint32_t)nF) H->misc[M_ERR] = 1; }
+    }
+    __syncthreads();
+    const uint32_t n_bc = H->misc[M_NBC];
+    const int used = (int)n_bc < P.ds ? (int)n_bc : P.ds;             // smCounter.py:489
+    smc_row* out = rows + li;
+    if (H->misc[M_ERR] || used == 0) {
+        // bad input, or the Zero_Coverage row (smCounter.py:492-494)
+        if (tid == 0) {
+            smc_row* R = rowst;   // zeroed in S0
+            R->status = H->misc[M_ERR] ? SMC_ST_BAD_INPUT : SMC_ST_ZERO_COVERAGE;
+            R->cvg = n;
+            R->all_mt = H->misc[M_ALLMT];
+            R->all_frag = H->misc[M_TOTFRAG];
+            R->max_allele = R->second_allele = -1;
+            for (int k = 0; k < 4; ++k) R->dp[k] = tal[k * SMC_NT + SMC_T_CNT];
+            for (int c = 0; c < 2; ++c) {
+                R->cand[c].allele = -1;
+                R->cand[c].p_sb = R->cand[c].p_r1 = R->cand[c].p_r2 = R->cand[c].p_pr = NAN;
+            }
+        }
+        __syncthreads();
+        const uint32_t* src = (const uint32_t*)rowst;
+        uint32_t* dst = (uint32_t*)out;
+        for (int i = tid; i < (int)(sizeof(smc_row) / 4); i += BLOCK) dst[i] = src[i];
+        return;
+    }
+
+    // ---- P2: fragment table. Included reads only (smCounter.py:467)
+    for (int base = 0; base < n; base += BLOCK) {
+        const int i = base + tid;
+        if (i < n) {
+            const uint32_t m = meta[i];
+            ReadRec r = decode_read(m, 0, P);
+            if (r.inc) {
+                const uint32_t s = umi_base[umi[i]] + frag[i];
+                const uint32_t key = make_key(i, r.allele, r.bq_eff);
+                atomicMin(&fmin[s], key);
+                atomicMax(&fmax[s], key);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- R1: do all fragments have <= 2 included reads?
+    {
+        uint32_t c = 0;
+        for (int s = tid; s < nF; s += BLOCK) {
+            const uint32_t a = fmin[s], b = fmax[s];
+            c += (a == 0xFFFFFFFFu) ? 0u : (a == b ? 1u : 2u);
+        }
+        c = wave_reduce_add((int)c, WAVE);
+        if (lane == 0 && c) atomicAdd(&H->misc[M_RESOLVED], c);
+    }
+    __syncthreads();
+    const bool need_fix = H->misc[M_RESOLVED] != H->misc[M_NINC];
+    if (need_fix) {
+        // some read name has >= 3 included alignments on this locus: mark those fragments
+        for (int base = 0; base < n; base += BLOCK) {
+            const int i = base + tid;
+            if (i < n) {
+                ReadRec r = decode_read(meta[i], 0, P);
+                if (r.inc) {
+                    const uint32_t s = umi_base[umi[i]] + frag[i];
+                    const uint32_t key = make_key(i, r.allele, r.bq_eff);
+                    const uint32_t lo = fmin[s], hi = fmax[s];
+                    if (key != lo && key != hi) fmax[s] = 0xFFFFFFFFu;   // idempotent marker
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- R2: mate merge for fragments with <= 2 included reads (smCounter.py:468-479)
+    for (int sb = 0; sb < nF; sb += BLOCK) {
+        const int s = sb + tid;
+        bool conc = false, disc = false;
+        int ev_allele = 0;
+        if (s < nF) {
+            const uint32_t a = fmin[s], b = fmax[s];
+            uint32_t st = 0;
+            if (b == 0xFFFFFFFFu) {
+                st = 0;   // replayed below
+            } else if (a != 0xFFFFFFFFu) {
+                const int a1 = KEY_ALLELE(a), q1 = KEY_BQ(a);
+                if (a == b) {
+                    st = make_state(a1, q1, false);
+                } else {
+                    const int a2 = KEY_ALLELE(b), q2 = KEY_BQ(b);
+                    if (a2 == a1 || a2 == N_ID) {
+                        // prob = max(prob_new, prob_old)  <=>  min quality  (:473)
+                        st = make_state(a1, q1 < q2 ? q1 : q2, true);
+                        if (a2 == a1) { conc = true; ev_allele = a1; }
+                    } else {
+                        st = 0;                                          // del bcDict[BC][readid] (:478)
+                        disc = true; ev_allele = a2;
+                    }
+                }
+            }
+            if (b != 0xFFFFFFFFu) fmin[s] = st;
+        }
+        if (__ballot(conc || disc)) {
+            if (conc) atomicAdd(&tal[ev_allele * SMC_NT + SMC_T_CONCORD], 1u);
+            if (disc) atomicAdd(&tal[ev_allele * SMC_NT + SMC_T_DISCORD], 1u);
+        }
+    }
+    __syncthreads();
+    if (need_fix) {
+        // sequential replay, one wave per marked fragment
+        constexpr int NW = BLOCK / WAVE;
+        for (int sb = 0; sb < nF; sb += 1) {
+            if (fmax[sb] != 0xFFFFFFFFu) continue;            // uniform over the block (LDS value)
+            if ((sb % NW) != wid) continue;                   // uniform over the wave
+            bool present = false, paired = false;
+            int sa = 0, sq = 0;
+            for (int base = 0; base < n; base += WAVE) {
+                const int i = base + lane;
+                bool hit = false;
+                ReadRec r;
+                r.allele = 0; r.bq_eff = 0;
+                if (i < n) {
+                    r = decode_read(meta[i], 0, P);
+                    hit = r.inc && (umi_base[umi[i]] + frag[i]) == (uint32_t)sb;
+                }
+                unsigned long long hm = __ballot(hit);
+                while (hm) {
+                    const int src = __ffsll((long long)hm) - 1;
+                    hm &= hm - 1;
+                    const int a = __shfl(r.allele, src), q = __shfl(r.bq_eff, src);
+                    if (!present) { present = true; paired = false; sa = a; sq = q; }
+                    else if (a == sa || a == N_ID) {
+                        sq = q < sq ? q : sq; paired = true;
+                        if (a == sa && lane == 0) atomicAdd(&tal[a * SMC_NT + SMC_T_CONCORD], 1u);
+                    } else {
+                        present = false;
+                        if (lane == 0) atomicAdd(&tal[a * SMC_NT + SMC_T_DISCORD], 1u);
+                    }
+                }
+            }
+            if (lane == 0) fmin[sb] = present ? make_state(sa, sq, paired) : 0u;
+        }
+        __syncthreads();
+    }
+
+    // ---- down-sampling stand-in (non-parity; the reference random.samples, :496-498):
+    // keep the `ds` lowest barcode ids among bcDict's keys.
+    if ((int)n_bc > P.ds) {
+        // rank of each flagged barcode = exclusive prefix count of flags; reuse fmax[] as scratch
+        // is not possible (nU may exceed nF), so count serially per thread block-stride: rare path.
+        if (tid == 0) {
+            int k = 0;
+            for (int u = 0; u < nU; ++u)
+                if (umi_flag[u]) { if (k >= P.ds) umi_flag[u] = 0; ++k; }
+        }
+        __syncthreads();
+    }
+
+    // ---- U: per-barcode posterior (calProb, :26-98) and PI / consensus accumulation (:506-532)
+    {
+        // lanes per barcode: power of two, enough groups to cover the barcodes
+        int G = 1;
+        while (G < WAVE && (BLOCK / (G * 2)) >= nU) G <<= 1;
+        const int grp = tid / G, j = tid % G, ngrp = BLOCK / G;
+        // fixed-point scale of the PI sums: order-independent, hence bit-reproducible
+        int bits = 32 - __clz(used);
+        int shift = 58 - bits; if (shift > 48) shift = 48;
+        const double fxscale = (double)(1ull << shift);
+        long long pi_acc[4] = {0, 0, 0, 0};
+        int mt_acc[4] = {0, 0, 0, 0}, st_acc[4] = {0, 0, 0, 0};
+        int c3 = 0, c5 = 0, c7 = 0, c10 = 0, ufrag = 0;
+        uint32_t touch_lo = 0, touch_hi = 0;
+        const double pne = 1.0 - 3e-5;                                 // pcr_no_error, :20
+
+        for (int u = grp; u < nU; u += ngrp) {
+            if (!umi_flag[u]) continue;                                // not a key of bcDict
+            const int b0 = umi_base[u], b1 = umi_base[u + 1];
+            // pass A: fragment count, allele set, P(no sequencing error)
+            int nf = 0;
+            uint32_t mlo = 0, mhi = 0;
+            double rightP = 1.0;
+            for (int s = b0 + j; s < b1; s += G) {
+                const uint32_t st = fmin[s];
+                if (st & ST_PRESENT) {
+                    ++nf;
+                    const int a = KEY_ALLELE(st);
+                    if (a < 32) mlo |= 1u << a; else mhi |= 1u << (a - 32);
+                    const double p = (st & ST_PAIRED) ? lut[KEY_BQ(st)] : 0.1;   // :65-68
+                    rightP *= 1.0 - p;
+                }
+            }
+            nf = wave_reduce_add(nf, G);
+            mlo = wave_reduce_or(mlo, G);
+            mhi = wave_reduce_or(mhi, G);
+            rightP = wave_reduce_mul(rightP, G);
+            const unsigned long long mask = ((unsigned long long)mhi << 32) | mlo;
+            if (j == 0) { ufrag += nf; c3 += nf >= 3; c5 += nf >= 5; c7 += nf >= 7; c10 += nf >= 10; }
+
+            if (nf <= P.mt_drop) {                                     // :28-32 -> all four posteriors 0
+                if (j == 0) {
+                    touch_lo |= 0xFu;                                  // finalDict gets A,T,G,C (+ -0.0)
+                    if (nf == 1) {                                     // tie -> single-fragment rule, :521-523
+                        const int a = __ffsll((long long)mask) - 1;
+                        if (a < 4) mt_acc[a]++; else atomicAdd(&mtc[a], 1u);
+                    }
+                }
+                continue;
+            }
+            const int n_exist = __popcll(mask);
+            int npad = n_exist < 4 ? 4 - n_exist : 0;
+            unsigned long long padmask = 0;
+            for (int a = 0, k = 0; a < 4 && k < npad; ++a)
+                if (!((mask >> a) & 1ull)) { padmask |= 1ull << a; ++k; }   // :49-54, atgc order
+            const int nk = n_exist + npad;
+            const double denom = nf + 0.5 * nk;                        // :80
+
+            if (n_exist <= 4) {
+                int ida[4] = {0, 0, 0, 0}, cnta[4] = {0, 0, 0, 0};
+                double proda[4] = {1.0, 1.0, 1.0, 1.0};
+                {
+                    unsigned long long mm = mask;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k < n_exist) { ida[k] = __ffsll((long long)mm) - 1; mm &= mm - 1; }
+                }
+                // pass B: per existing allele, count and P(reads | allele)  (:62-77)
+                for (int s = b0 + j; s < b1; s += G) {
+                    const uint32_t st = fmin[s];
+                    if (st & ST_PRESENT) {
+                        const int a = KEY_ALLELE(st);
+                        const double p = (st & ST_PAIRED) ? lut[KEY_BQ(st)] : 0.1;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (k < n_exist) {
+                                const bool same = a == ida[k];
+                                cnta[k] += same;
+                                proda[k] *= same ? 1.0 - p : p;
+                            }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    cnta[k] = wave_reduce_add(cnta[k], G);
+                    proda[k] = wave_reduce_mul(proda[k], G);
+                }
+                // PCR-error terms (:79-81); min over the other keys == value at their max count
+                int max1 = -1, max2 = -1, arg1 = -1;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < n_exist) {
+                        if (cnta[k] > max1) { max2 = max1; max1 = cnta[k]; arg1 = k; }
+                        else if (cnta[k] > max2) max2 = cnta[k];
+                    }
+                double prodpcr = 1.0, tmpv[4] = {0, 0, 0, 0}, sumP = 0.0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < n_exist) prodpcr *= pcr_of(cnta[k], denom);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < n_exist) {
+                        int other = (k == arg1) ? max2 : max1;
+                        if (npad > 0 && other < 0) other = 0;
+                        if (npad > 0 && other < 0) other = 0;
+                        tmpv[k] = pne * proda[k] + rightP * pcr_of(other < 0 ? 0 : other, denom);   // :86
+                        sumP += tmpv[k];
+                    }
+                const double padOut = rightP * prodpcr;                // :88-91
+                for (int k = 0; k < npad; ++k) sumP += padOut;
+                // posteriors -> -log10(1-p) (:95-96, :508-510)
+                double predv[4] = {0, 0, 0, 0}, mx = -1.0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < n_exist) {
+                        const double post = sumP <= 0 ? 0.0 : tmpv[k] / sumP;
+                        const double x = 1.0 - post;
+                        predv[k] = x > 0.0 ? -log10(x) : 16.0;
+                        if (predv[k] > mx) mx = predv[k];
+                    }
+                double predpad = 0.0;
+                if (npad) {
+                    const double post = sumP <= 0 ? 0.0 : padOut / sumP;
+                    const double x = 1.0 - post;
+                    predpad = x > 0.0 ? -log10(x) : 16.0;
+                    if (predpad > mx) mx = predpad;
+                }
+                if (j == 0) {
+                    int n_max = 0, cons = -1;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k < n_exist) {
+                            const int a = ida[k];
+                            const long long fx = (long long)(predv[k] * fxscale + 0.5);
+                            if (a < 4) pi_acc[a] += fx; else atomicAdd(&pifx[a], (unsigned long long)fx);
+                            if (predv[k] == mx) { ++n_max; cons = a; }                 // :514
+                        }
+                    if (npad) {
+                        const long long fx = (long long)(predpad * fxscale + 0.5);
+#pragma unroll
+                        for (int a = 0; a < 4; ++a)
+                            if ((padmask >> a) & 1ull) {
+                                pi_acc[a] += fx;
+                                if (predpad == mx) { ++n_max; cons = a; }
+                            }
+                    }
+                    const unsigned long long uq = mask | padmask;
+                    touch_lo |= (uint32_t)uq; touch_hi |= (uint32_t)(uq >> 32);
+                    if (n_max == 1) {                                                    // :515-519
+                        const bool str = mx > P.smt;
+                        if (cons < 4) { mt_acc[cons]++; st_acc[cons] += str; }
+                        else { atomicAdd(&mtc[cons], 1u); if (str) atomicAdd(&strong[cons], 1u); }
+                    } else if (nf == 1) {                                                // :521-523
+                        const int a = ida[0];
+                        if (a < 4) mt_acc[a]++; else atomicAdd(&mtc[a], 1u);
+                    }
+                }
+            } else {
+                // > 4 distinct alleles inside one barcode: same arithmetic, recomputed per allele
+                // instead of cached in registers.
+                auto scan_allele = [&](int a, int& cnt, double& prod) {
+                    cnt = 0; prod = 1.0;
+                    for (int s = b0 + j; s < b1; s += G) {
+                        const uint32_t st = fmin[s];
+                        if (st & ST_PRESENT) {
+                            const double p = (st & ST_PAIRED) ? lut[KEY_BQ(st)] : 0.1;
+                            const bool same = (int)KEY_ALLELE(st) == a;
+                            cnt += same;
+                            prod *= same ? 1.0 - p : p;
+                        }
+                    }
+                    cnt = wave_reduce_add(cnt, G);
+                    prod = wave_reduce_mul(prod, G);
+                };
+                int max1 = -1, max2 = -1, arg1 = -1;
+                double prodpcr = 1.0;
+                for (unsigned long long mm = mask; mm; mm &= mm - 1) {
+                    const int a = __ffsll((long long)mm) - 1;
+                    int c; double pr;
+                    scan_allele(a, c, pr);
+                    if (c > max1) { max2 = max1; max1 = c; arg1 = a; }
+                    else if (c > max2) max2 = c;
+                    prodpcr *= pcr_of(c, denom);
+                }
+                double sumP = 0.0;
+                for (unsigned long long mm = mask; mm; mm &= mm - 1) {
+                    const int a = __ffsll((long long)mm) - 1;
+                    int c; double pr;
+                    scan_allele(a, c, pr);
+                    const int other = (a == arg1) ? max2 : max1;
+                    sumP += pne * pr + rightP * pcr_of(other, denom);
+                }
+                double mx = -1.0;
+                int n_max = 0, cons = -1;
+                for (unsigned long long mm = mask; mm; mm &= mm - 1) {
+                    const int a = __ffsll((long long)mm) - 1;
+                    int c; double pr;
+                    scan_allele(a, c, pr);
+                    const int other = (a == arg1) ? max2 : max1;
+                    const double t = pne * pr + rightP * pcr_of(other, denom);
+                    const double post = sumP <= 0 ? 0.0 : t / sumP;
+                    const double x = 1.0 - post;
+                    const double pred = x > 0.0 ? -log10(x) : 16.0;
+                    if (pred > mx) { mx = pred; n_max = 1; cons = a; }
+                    else if (pred == mx) ++n_max;
+                    if (j == 0) {
+                        const long long fx = (long long)(pred * fxscale + 0.5);
+                        if (a < 4) pi_acc[a] += fx; else atomicAdd(&pifx[a], (unsigned long long)fx);
+                    }
+                }
+                if (j == 0) {
+                    touch_lo |= (uint32_t)mask; touch_hi |= (uint32_t)(mask >> 32);
+                    if (n_max == 1) {
+                        const bool str = mx > P.smt;
+                        if (cons < 4) { mt_acc[cons]++; st_acc[cons] += str; }
+                        else { atomicAdd(&mtc[cons], 1u); if (str) atomicAdd(&strong[cons], 1u); }
+                    }
+                }
+            }
+        }
+        // flush lane accumulators (order-independent integer adds)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const long long p = wave_reduce_add64(pi_acc[a], WAVE);
+            const int m = wave_reduce_add(mt_acc[a], WAVE), s = wave_reduce_add(st_acc[a], WAVE);
+            if (lane == 0) {
+                if (p) atomicAdd(&pifx[a], (unsigned long long)p);
+                if (m) atomicAdd(&mtc[a], (uint32_t)m);
+                if (s) atomicAdd(&strong[a], (uint32_t)s);
+            }
+        }
+        c3 = wave_reduce_add(c3, WAVE); c5 = wave_reduce_add(c5, WAVE);
+        c7 = wave_reduce_add(c7, WAVE); c10 = wave_reduce_add(c10, WAVE);
+        ufrag = wave_reduce_add(ufrag, WAVE);
+        touch_lo = wave_reduce_or(touch_lo, WAVE); touch_hi = wave_reduce_or(touch_hi, WAVE);
+        if (lane == 0) {
+            atomicAdd(&H->misc[M_MT3], (uint32_t)c3); atomicAdd(&H->misc[M_MT5], (uint32_t)c5);
+            atomicAdd(&H->misc[M_MT7], (uint32_t)c7); atomicAdd(&H->misc[M_MT10], (uint32_t)c10);
+            atomicAdd(&H->misc[M_USEDFRAG], (uint32_t)ufrag);
+            atomicOr(&H->misc[M_TOUCH_LO], touch_lo); atomicOr(&H->misc[M_TOUCH_HI], touch_hi);
+        }
+        __syncthreads();
+
+        // ---- E: ranking and candidates (:534-555), one thread
+        if (tid == 0) {
+            smc_row* R = rowst;   // zeroed in S0
+            const unsigned long long touched = ((unsigned long long)H->misc[M_TOUCH_HI] << 32) | H->misc[M_TOUCH_LO];
+            const int nkeys = __popcll(touched);
+            const double inv = 1.0 / fxscale;
+            auto PI = [&](int a) { return (double)(long long)pifx[a] * inv; };
+            auto rank = [&](int a) {
+                const int r8[6] = {0, 5, 6, 2, 7, 4}, r32[6] = {0, 21, 6, 2, 15, 20};
+                return a < 6 ? (nkeys <= 5 ? r8[a] : r32[a]) : 64 + a;
+            };
+            int best = -1, second = -1;
+            for (int pass = 0; pass < 2; ++pass) {
+                int pick = -1;
+                double ppi = 0.0;
+                for (int a = 0; a < nA; ++a) {
+                    if (!((touched >> a) & 1ull) || a == best) continue;
+                    const double v = PI(a);
+                    if (pick < 0 || v > ppi || (v == ppi && rank(a) < rank(pick))) { pick = a; ppi = v; }
+                }
+                if (pass == 0) best = pick; else second = pick;
+            }
+            R->status = ((int)n_bc > P.ds) ? SMC_ST_DOWNSAMPLED : SMC_ST_OK;
+            R->n_touched = nkeys;
+            R->cvg = n;
+            R->all_frag = H->misc[M_TOTFRAG];
+            R->all_mt = H->misc[M_ALLMT];
+            R->used_frag = H->misc[M_USEDFRAG];
+            R->used_mt = used;
+            R->mt3 = H->misc[M_MT3]; R->mt5 = H->misc[M_MT5]; R->mt7 = H->misc[M_MT7]; R->mt10 = H->misc[M_MT10];
+            R->max_allele = best; R->second_allele = second;
+            R->touched_mask = touched;
+            for (int k = 0; k < 4; ++k) {
+                R->dp[k] = tal[k * SMC_NT + SMC_T_CNT];
+                R->umt[k] = mtc[k];
+                R->vsm[k] = strong[k];
+                R->pi[k] = PI(k);
+            }
+            const int ref = L.ref_allele;
+            if (ref < nA) for (int k = 0; k < SMC_NT; ++k) R->ref_tal[k] = tal[ref * SMC_NT + k];
+            auto fill = [&](smc_cand& C, int a) {
+                C.allele = a;
+                C.p_sb = C.p_r1 = C.p_r2 = C.p_pr = NAN;
+                if (a < 0) return;
+                C.pi = PI(a);
+                C.vdp = tal[a * SMC_NT + SMC_T_CNT];
+                C.vmt = mtc[a];
+                C.vsm = strong[a];
+                for (int k = 0; k < SMC_NT; ++k) C.tal[k] = tal[a * SMC_NT + k];
+            };
+            auto filterable = [&](int a) { return ((L.snp_mask >> a) & 1ull) || a != GAP_ID; };  // SNP or INDEL
+            const int alt = best == ref ? second : best;                                   // :541
+            fill(R->cand[0], alt);
+            if (alt >= 0 && R->cand[0].pi >= 5 && filterable(alt)) R->cand[0].flt_applied = 1;   // :549
+            const double mf1 = best >= 0 ? 1.0 * mtc[best] / used : 0.0;
+            const double mf2 = second >= 0 ? 1.0 * mtc[second] / used : 0.0;
+            if (best >= 0 && second >= 0 && best != ref && second != ref && mf1 >= 0.45 && mf2 >= 0.45) {   // :555
+                R->biallelic = 1;
+                fill(R->cand[1], second);
+                if (R->cand[1].pi >= 5 && filterable(second)) R->cand[1].flt_applied = 1;   // :563
+            } else {
+                fill(R->cand[1], -1);
+            }
+        }
+        __syncthreads();
+        const uint32_t* src = (const uint32_t*)rowst;
+        uint32_t* dst = (uint32_t*)out;
+        for (int i = tid; i < (int)(sizeof(smc_row) / 4); i += BLOCK) dst[i] = src[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// kernel 2: filterVariants (smCounter.py:182-269), one wave per locus, only where it applies
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double d_lchoose(double n, double k) {
+    return lgamma(n + 1.0) - lgamma(k + 1.0) - lgamma(n - k + 1.0);
+}
+
+// scipy.stats.fisher_exact(table) two-sided, evaluated by one wavefront: the support is cut into
+// 64 contiguous chunks, each lane anchors its chunk with one lgamma-based pmf and walks it with the
+// exact ratio pmf(k+1)/pmf(k) = (n1-k)(n-k) / ((k+1)(n2-n+k+1)).
+__device__ void wave_fisher(long long a, long long b, long long c, long long d, double* orat, double* pval) {
+    const int lane = threadIdx.x & 63;
+    if (a + b == 0 || c + d == 0 || a + c == 0 || b + d == 0) { *orat = NAN; *pval = 1.0; return; }
+    *orat = (c > 0 && b > 0) ? ((double)(a * d)) / ((double)(c * b)) : INFINITY;
+    const long long n1 = a + b, n2 = c + d, n = a + c;
+    const long long lo = n - n2 > 0 ? n - n2 : 0, hi = n < n1 ? n : n1;
+    const double lden = d_lchoose((double)(n1 + n2), (double)n);
+    const double pexact = exp(d_lchoose((double)n1, (double)a) + d_lchoose((double)n2, (double)(n - a)) - lden);
+    const double thr = pexact * (1.0 + 1e-7);
+    const long long len = hi - lo + 1, chunk = (len + 63) / 64;
+    const long long k0 = lo + chunk * lane, k1 = (k0 + chunk - 1 < hi) ? k0 + chunk - 1 : hi;
+    double p = 0.0;
+    if (k0 <= hi) {
+        double pk = exp(d_lchoose((double)n1, (double)k0) + d_lchoose((double)n2, (double)(n - k0)) - lden);
+        for (long long k = k0;; ++k) {
+            if (pk <= thr) p += pk;
+            if (k == k1) break;
+            pk *= ((double)(n1 - k) * (double)(n - k)) / ((double)(k + 1) * (double)(n2 - n + k + 1));
+        }
+    }
+    for (int m = 1; m < 64; m <<= 1) p += __shfl_xor(p, m);
+    *pval = p < 1.0 ? p : 1.0;
+}
+
+__global__ __launch_bounds__(WAVE) void k_filter_loci(KParams P, const smc_locus* __restrict__ loci, smc_row* __restrict__ rows, int n_loci) {
+    const int li = blockIdx.x;
+    if (li >= n_loci) return;
+    smc_row* R = rows + li;
+    if ((R->status & 0xff) != SMC_ST_OK) return;
+    const smc_locus L = loci[li];
+    const int lane = threadIdx.x;
+    for (int ci = 0; ci < 2; ++ci) {
+        smc_cand* C = &R->cand[ci];
+        if (C->allele < 0 || !C->flt_applied) continue;        // wave-uniform
+        const int alt = C->allele;
+        const bool snp = (L.snp_mask >> alt) & 1ull;
+        const int* ta = C->tal;
+        const int* tr = R->ref_tal;
+        uint32_t f = 0;
+        if (R->used_mt < 5) f |= SMC_F_LM;                                        // :187
+        if (C->vsm < 2) f |= SMC_F_LSM;                                           // :191
+        const int vmf = (1.0 * C->vmt / R->used_mt < 0.99);                       // :198,:202
+        const double af_alt = 100.0 * ta[SMC_T_CNT] / R->cvg;                     // :206
+        const int pairs = ta[SMC_T_DISCORD] + ta[SMC_T_CONCORD];                  // :207
+        double p_sb = NAN, p_r1 = NAN, p_r2 = NAN, p_pr = NAN, orat, p;
+        if (pairs >= 1000 && 1.0 * ta[SMC_T_DISCORD] / pairs >= 0.5) {
+            f |= SMC_F_DP;                                                        // :208-209
+        } else if (af_alt <= 60.0) {
+            wave_fisher(tr[SMC_T_REV], tr[SMC_T_FWD], ta[SMC_T_REV], ta[SMC_T_FWD], &orat, &p);   // :211-215
+            p_sb = p;
+            if (p < 0.00001 && (orat >= 50 || orat <= 1.0 / 50)) f |= SMC_F_SB;
+        }
+        double bq_alt = 0.0;                                                      // :222-227
+        if (snp && ta[SMC_T_LOWQ] > 0) bq_alt = 1.0 * ta[SMC_T_LOWQ] / ta[SMC_T_CNT];
+        if (bq_alt > 0.4) f |= SMC_F_LOWQ;
+        if (snp) {                                                                // :230-266
+            wave_fisher(tr[SMC_T_R1LE], tr[SMC_T_R1N] - tr[SMC_T_R1LE], ta[SMC_T_R1LE], ta[SMC_T_R1N] - ta[SMC_T_R1LE], &orat, &p);
+            p_r1 = p;
+            if (p < 0.001 && orat < 0.05 && af_alt <= 60.0) f |= SMC_F_R1CP;
+            wave_fisher(tr[SMC_T_R2BCLE], tr[SMC_T_R2N] - tr[SMC_T_R2BCLE], ta[SMC_T_R2BCLE], ta[SMC_T_R2N] - ta[SMC_T_R2BCLE], &orat, &p);
+            p_r2 = p;
+            if (p < 0.001 && orat < 0.05 && af_alt <= 60.0) f |= SMC_F_R2CP;
+            const int alt_le = ta[SMC_T_R2PRLE], alt_gt = ta[SMC_T_R2N] - ta[SMC_T_R2PRLE];
+            wave_fisher(tr[SMC_T_R2PRLE], tr[SMC_T_R2N] - tr[SMC_T_R2PRLE], alt_le, alt_gt, &orat, &p);
+            p_pr = p;
+            if (alt_le + alt_gt > 0)
+                if (1.0 * alt_le / (alt_le + alt_gt) >= 0.98 || (p < 0.001 && orat < 1.0 / 20)) f |= SMC_F_PRIMERCP;
+        }
+        if (lane == 0) {
+            C->flt = f; C->vmf_lt_099 = vmf;
+            C->p_sb = p_sb; C->p_r1 = p_r1; C->p_r2 = p_r2; C->p_pr = p_pr;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side: C ABI
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(x)                                                                                   \
+    do {                                                                                            \
+        hipError_t e_ = (x);                                                                        \
+        if (e_ != hipSuccess)                                                                       \
+            return fail(SMC_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_));                 \
+    } while (0)
+
+struct smc_ctx {
+    int device;
+    double* lut;   // 10^(-q/10), q = 0..255
+    int max_lds;   // bytes of LDS a workgroup may use
+};
+
+static size_t host_hdr_bytes(int a_cap) {
+    return sizeof(Hdr) + (size_t)a_cap * SMC_NT * 4 + (size_t)a_cap * 8 + (size_t)a_cap * 4 + (size_t)a_cap * 4 + sizeof(smc_row);
+}
+static size_t table_bytes(const smc_locus& L) {
+    size_t b = 4 * ((size_t)L.n_umi + 1) + 8 * (size_t)L.n_frag + (size_t)L.n_umi;
+    return (b + 15) & ~(size_t)15;
+}
+
+struct Bin {
+    int cls;              // 0: 64 thr, 1: 256, 2: 512, 3: 1024 (LDS tables), 4: 1024 (global tables)
+    int a_cap;
+    size_t lds_bytes;
+    std::vector<int> order;
+    int* d_order = nullptr;
+    int64_t* d_scratch_off = nullptr;
+    uint8_t* d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+};
+
+struct smc_plan {
+    smc_ctx* ctx;
+    int64_t n_loci;
+    smc_locus* d_loci = nullptr;
+    std::vector<Bin> bins;
+};
+
+template <int BLOCK, bool GT>
+static hipError_t launch_bin(const Bin& b, const KParams& kp, const smc_plan* p, const uint32_t* meta, const uint32_t* umi,
+                             const uint32_t* frag, const uint32_t* dist, smc_row* rows, hipStream_t st) {
+    auto kern = k_call_loci<BLOCK, GT>;
+    if (b.lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b.lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)b.order.size()), dim3(BLOCK), b.lds_bytes, st, kp, p->d_loci, b.d_order, b.a_cap,
+                       meta, umi, frag, dist, p->ctx->lut, rows, b.d_scratch, b.d_scratch_off);
+    return hipGetLastError();
+}
+
+extern "C" {
+
+int smc_abi_version(void) { return SMC_ABI_VERSION; }
+const char* smc_last_error(void) { return g_err.c_str(); }
+int smc_row_size(void) { return (int)sizeof(smc_row); }
+int smc_locus_size(void) { return (int)sizeof(smc_locus); }
+
+int smc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int smc_create(int device, smc_ctx** out) {
+    if (!out) return fail(SMC_E_ARG, "smc_create: out is NULL");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(SMC_E_NOGPU, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(SMC_E_ARG, "smc_create: device index out of range");
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(SMC_E_NOGPU, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    smc_ctx* c = new smc_ctx();
+    c->device = device;
+    c->max_lds = 160 * 1024;
+    double h[256];
+    for (int q = 0; q < 256; ++q) h[q] = pow(10.0, -q / 10.0);   // smCounter.py:469
+    HIPCHK(hipMalloc(&c->lut, sizeof h));
+    HIPCHK(hipMemcpy(c->lut, h, sizeof h, hipMemcpyHostToDevice));
+    *out = c;
+    return SMC_OK;
+}
+
+void smc_destroy(smc_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipFree(c->lut);
+    delete c;
+}
+
+void smc_plan_destroy(smc_plan* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipFree(p->d_loci);
+    for (auto& b : p->bins) {
+        (void)hipFree(b.d_order);
+        (void)hipFree(b.d_scratch_off);
+        (void)hipFree(b.d_scratch);
+    }
+    delete p;
+}
+
+int smc_plan_create(smc_ctx* ctx, const smc_locus* loci, int64_t n_loci, smc_plan** out) {
+    if (!ctx || !out || (n_loci > 0 && !loci)) return fail(SMC_E_ARG, "smc_plan_create: NULL argument");
+    if (n_loci > 0x7fffffff) return fail(SMC_E_ARG, "smc_plan_create: more than 2^31-1 loci in one batch");
+    HIPCHK(hipSetDevice(ctx->device));
+    smc_plan* p = new smc_plan();
+    p->ctx = ctx;
+    p->n_loci = n_loci;
+    static const size_t cls_cap[4] = {8 * 1024, 24 * 1024, 64 * 1024, 160 * 1024};
+    std::vector<Bin> bins(5);
+    for (int c = 0; c < 5; ++c) { bins[c].cls = c; bins[c].a_cap = 8; bins[c].lds_bytes = 0; }
+    for (int64_t l = 0; l < n_loci; ++l) {
+        const smc_locus& L = loci[l];
+        if (L.n_alleles > SMC_MAX_ALLELES || L.n_reads < 0 || L.n_umi < 0 || L.n_frag < 0 || (L.read_off & 3) ||
+            L.n_reads >= (1 << 18)) {
+            delete p;
+            return fail(SMC_E_INPUT, "smc_plan_create: locus " + std::to_string(l) +
+                                         " violates the layout contract (alleles<=64, reads<2^18, read_off%4==0)");
+        }
+        const int a_cap = (L.n_alleles + 7) & ~7;
+        const size_t need = host_hdr_bytes(a_cap < 8 ? 8 : a_cap) + table_bytes(L);
+        int c = 4;
+        for (int k = 0; k < 4; ++k)
+            if (need <= cls_cap[k]) { c = k; break; }
+        Bin& b = bins[c];
+        b.order.push_back((int)l);
+        if (a_cap > b.a_cap) b.a_cap = a_cap;
+    }
+    if (n_loci) {
+        HIPCHK(hipMalloc(&p->d_loci, sizeof(smc_locus) * (size_t)n_loci));
+        HIPCHK(hipMemcpy(p->d_loci, loci, sizeof(smc_locus) * (size_t)n_loci, hipMemcpyHostToDevice));
+    }
+    for (auto& b : bins) {
+        if (b.order.empty()) continue;
+        // heaviest loci first: the tail of the launch is then made of light blocks
+        std::stable_sort(b.order.begin(), b.order.end(), [&](int x, int y) { return loci[x].n_reads > loci[y].n_reads; });
+        size_t mx = 0;
+        std::vector<int64_t> soff;
+        for (int l : b.order) {
+            const size_t t = table_bytes(loci[l]);
+            if (b.cls == 4) { soff.push_back((int64_t)b.scratch_bytes); b.scratch_bytes += t; }
+            if (t > mx) mx = t;
+        }
+        b.lds_bytes = host_hdr_bytes(b.a_cap) + (b.cls == 4 ? 0 : mx);
+        b.lds_bytes = (b.lds_bytes + 255) & ~(size_t)255;
+        HIPCHK(hipMalloc(&b.d_order, sizeof(int) * b.order.size()));
+        HIPCHK(hipMemcpy(b.d_order, b.order.data(), sizeof(int) * b.order.size(), hipMemcpyHostToDevice));
+        if (b.cls == 4) {
+            HIPCHK(hipMalloc(&b.d_scratch_off, sizeof(int64_t) * soff.size()));
+            HIPCHK(hipMemcpy(b.d_scratch_off, soff.data(), sizeof(int64_t) * soff.size(), hipMemcpyHostToDevice));
+            HIPCHK(hipMalloc(&b.d_scratch, b.scratch_bytes));
+        }
+        p->bins.push_back(b);
+    }
+    *out = p;
+    return SMC_OK;
+}
+
+int smc_plan_info(const smc_plan* p, int32_t* n_launches, int64_t* scratch_bytes) {
+    if (!p) return fail(SMC_E_ARG, "smc_plan_info: NULL plan");
+    if (n_launches) *n_launches = (int32_t)p->bins.size() + (p->n_loci ? 1 : 0);
+    if (scratch_bytes) {
+        int64_t s = 0;
+        for (auto& b : p->bins) s += (int64_t)b.scratch_bytes;
+        *scratch_bytes = s;
+    }
+    return SMC_OK;
+}
+
+int smc_plan_run(smc_plan* p, const smc_params* prm, const uint32_t* meta, const uint32_t* umi, const uint32_t* frag,
+                 const uint32_t* dist, smc_row* rows, void* stream) {
+    if (!p || !prm) return fail(SMC_E_ARG, "smc_plan_run: NULL argument");
+    if (p->n_loci == 0) return SMC_OK;
+    if (!meta || !umi || !frag || !dist || !rows) return fail(SMC_E_ARG, "smc_plan_run: NULL device pointer");
+    HIPCHK(hipSetDevice(p->ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    KParams kp{prm->min_bq, prm->min_mq, prm->mt_drop, prm->primer_dist, prm->ds, prm->smt};
+    for (const Bin& b : p->bins) {
+        hipError_t e = hipSuccess;
+        switch (b.cls) {
+            case 0: e = launch_bin<64, false>(b, kp, p, meta, umi, frag, dist, rows, st); break;
+            case 1: e = launch_bin<256, false>(b, kp, p, meta, umi, frag, dist, rows, st); break;
+            case 2: e = launch_bin<512, false>(b, kp, p, meta, umi, frag, dist, rows, st); break;
+            case 3: e = launch_bin<1024, false>(b, kp, p, meta, umi, frag, dist, rows, st); break;
+            default: e = launch_bin<1024, true>(b, kp, p, meta, umi, frag, dist, rows, st); break;
+        }
+        if (e != hipSuccess) return fail(SMC_E_HIP, std::string("k_call_loci launch: ") + hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(k_filter_loci, dim3((unsigned)p->n_loci), dim3(WAVE), 0, st, kp, p->d_loci, rows, (int)p->n_loci);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SMC_E_HIP, std::string("k_filter_loci launch: ") + hipGetErrorString(e));
+    return SMC_OK;
+}
+
+int smc_call_batch_host(smc_ctx* ctx, const smc_params* prm, const smc_locus* loci, int64_t n_loci, const uint32_t* meta,
+                        const uint32_t* umi, const uint32_t* frag, const uint32_t* dist, int64_t n_slots, smc_row* rows_out) {
+    if (!ctx || !prm || (n_loci && (!loci || !rows_out))) return fail(SMC_E_ARG, "smc_call_batch_host: NULL argument");
+    if (n_loci == 0) return SMC_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    smc_plan* plan = nullptr;
+    int rc = smc_plan_create(ctx, loci, n_loci, &plan);
+    if (rc) return rc;
+    uint32_t* d[4] = {nullptr, nullptr, nullptr, nullptr};
+    const uint32_t* h[4] = {meta, umi, frag, dist};
+    smc_row* d_rows = nullptr;
+    const size_t pb = sizeof(uint32_t) * (size_t)(n_slots > 0 ? n_slots : 1);
+    auto cleanup = [&]() {
+        for (auto q : d) (void)hipFree(q);
+        (void)hipFree(d_rows);
+        smc_plan_destroy(plan);
+    };
+    for (int k = 0; k < 4; ++k) {
+        hipError_t e = hipMalloc(&d[k], pb);
+        if (e == hipSuccess && n_slots > 0) e = hipMemcpy(d[k], h[k], sizeof(uint32_t) * (size_t)n_slots, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { cleanup(); return fail(SMC_E_HIP, std::string("plane upload: ") + hipGetErrorString(e)); }
+    }
+    hipError_t e = hipMalloc(&d_rows, sizeof(smc_row) * (size_t)n_loci);
+    if (e != hipSuccess) { cleanup(); return fail(SMC_E_HIP, std::string("rows alloc: ") + hipGetErrorString(e)); }
+    rc = smc_plan_run(plan, prm, d[0], d[1], d[2], d[3], d_rows, nullptr);
+    if (rc == SMC_OK) {
+        e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipMemcpy(rows_out, d_rows, sizeof(smc_row) * (size_t)n_loci, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(SMC_E_HIP, std::string("run/download: ") + hipGetErrorString(e));
+    }
+    cleanup();
+    return rc;
+}
+
+int smc_event_create(void** ev) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    *ev = (void*)e;
+    return SMC_OK;
+}
+int smc_event_record(void* ev, void* stream) {
+    HIPCHK(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+    return SMC_OK;
+}
+int smc_event_elapsed_ms(void* start, void* stop, float* ms) {
+    HIPCHK(hipEventSynchronize((hipEvent_t)stop));
+    HIPCHK(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return SMC_OK;
+}
+void smc_event_destroy(void* ev) { (void)hipEventDestroy((hipEvent_t)ev); }
+
+}  // extern "C"

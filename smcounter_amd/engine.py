@@ -1,0 +1,93 @@
+"""Host driver of the HIP path: one `Engine` per process / GPU.
+
+Mirrors the reference's dispatch (smCounter.py:683-685: one task per locus, results in input
+order) as one batched launch over an SoA batch.  PyTorch is used only to own device memory and
+streams; every compute call goes through the C ABI (include/smcounter_hip.h).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib, abi
+from .features import DeviceBatch
+from .params import VcParams
+
+
+class Engine(object):
+    def __init__(self, device: int = 0):
+        self.L = _lib.load()
+        if self.L.smc_device_count() <= 0:
+            raise _lib.SmcError("no HIP device visible; the smCounter HIP path needs an MI355X (gfx950)")
+        self.device = device
+        h = ctypes.c_void_p()
+        _lib.check(self.L.smc_create(device, ctypes.byref(h)), "smc_create")
+        self.ctx = h
+
+    def close(self):
+        if self.ctx:
+            self.L.smc_destroy(self.ctx)
+            self.ctx = None
+
+    # ---- pure C-ABI path: host buffers in, host rows out
+    def call_batch_host(self, db: DeviceBatch, params: VcParams) -> np.ndarray:
+        rows = np.zeros(db.n_loci, abi.ROW_DTYPE)
+        cp = abi.c_params(params)
+        loci = np.ascontiguousarray(db.loci)
+        planes = [np.ascontiguousarray(x, np.uint32) for x in (db.meta, db.umi, db.frag, db.dist)]
+        _lib.check(self.L.smc_call_batch_host(
+            self.ctx, ctypes.byref(cp), loci.ctypes.data, db.n_loci,
+            planes[0].ctypes.data, planes[1].ctypes.data, planes[2].ctypes.data, planes[3].ctypes.data,
+            db.n_slots, rows.ctypes.data), "smc_call_batch_host")
+        return rows
+
+    # ---- resident path: planes live in HBM (torch tensors), a plan is reused across runs
+    def upload(self, db: DeviceBatch):
+        import torch
+        dev = torch.device("cuda", self.device)
+        return [torch.from_numpy(np.ascontiguousarray(x).view(np.int32)).to(dev)
+                for x in (db.meta, db.umi, db.frag, db.dist)]
+
+    def make_plan(self, loci: np.ndarray):
+        loci = np.ascontiguousarray(loci)
+        h = ctypes.c_void_p()
+        _lib.check(self.L.smc_plan_create(self.ctx, loci.ctypes.data, len(loci), ctypes.byref(h)),
+                   "smc_plan_create")
+        return Plan(self, h, len(loci))
+
+
+class Plan(object):
+    def __init__(self, eng: Engine, handle, n_loci: int):
+        self.eng, self.h, self.n_loci = eng, handle, n_loci
+
+    def info(self):
+        nl, sb = ctypes.c_int32(), ctypes.c_int64()
+        _lib.check(self.eng.L.smc_plan_info(self.h, ctypes.byref(nl), ctypes.byref(sb)), "smc_plan_info")
+        return nl.value, sb.value
+
+    def alloc_rows(self):
+        import torch
+        return torch.empty(self.n_loci * abi.ROW_DTYPE.itemsize, dtype=torch.uint8,
+                           device=torch.device("cuda", self.eng.device))
+
+    def run(self, planes, params: VcParams, rows=None, stream=None):
+        """Enqueue the hot path on `stream` (a torch.cuda.Stream; default: torch's current one)."""
+        import torch
+        if rows is None:
+            rows = self.alloc_rows()
+        st = stream if stream is not None else torch.cuda.current_stream(self.eng.device)
+        cp = abi.c_params(params)
+        _lib.check(self.eng.L.smc_plan_run(self.h, ctypes.byref(cp), planes[0].data_ptr(), planes[1].data_ptr(),
+                                           planes[2].data_ptr(), planes[3].data_ptr(), rows.data_ptr(),
+                                           ctypes.c_void_p(st.cuda_stream)), "smc_plan_run")
+        return rows
+
+    @staticmethod
+    def download(rows) -> np.ndarray:
+        return rows.cpu().numpy().view(abi.ROW_DTYPE)
+
+    def close(self):
+        if self.h:
+            self.eng.L.smc_plan_destroy(self.h)
+            self.h = None

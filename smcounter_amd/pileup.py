@@ -112,3 +112,25 @@ def allele_kind(s: str) -> str:
     if s.split("|")[0] in ("DEL", "INS"):
         return "INDEL"
     return "."
+
+
+_PER_READ = ("umi", "frag", "flag", "mq", "nm", "n_indel", "left_sp", "qlen", "qalen", "qpos", "indel",
+             "is_del", "allele", "bq")
+
+
+def save_npz(path: str, pb: PileupBatch, **extra):
+    """Compact on-disk form of a batch (used for the golden fixtures under tests/golden/)."""
+    import json
+    meta = dict(chrom=pb.chrom, ref=pb.ref, alleles=pb.alleles, extra=extra)
+    arrays = {k: getattr(pb, k) for k in _PER_READ}
+    np.savez_compressed(path, pos=pb.pos, read_off=pb.read_off,
+                        meta=np.frombuffer(json.dumps(meta).encode(), np.uint8), **arrays)
+
+
+def load_npz(path: str):
+    import json
+    z = np.load(path)
+    meta = json.loads(bytes(z["meta"]).decode())
+    pb = PileupBatch(chrom=meta["chrom"], pos=z["pos"], ref=meta["ref"], alleles=meta["alleles"],
+                     read_off=z["read_off"], **{k: z[k] for k in _PER_READ})
+    return pb, meta["extra"]

@@ -233,3 +233,173 @@ def generate(cfg: SynthConfig, lo: int = 0, hi: int = None, return_counts: bool 
     if return_counts:
         return pb, (np.full(nl, U, np.int64), n_frag_u.sum(axis=1).astype(np.int64))
     return pb
+
+
+# ---------------------------------------------------------------------------------------------
+# Stress generator: small loci that walk every branch of vc()/filterVariants (edge cases the
+# reference handles: empty and all-filtered loci, N bases, discordant and triple-aligned
+# fragments, indel alleles, strand / read-end / primer-end clustering, bi-allelic loci,
+# homopolymer and low-complexity context, unflagged reads, missing NM tags).
+# ---------------------------------------------------------------------------------------------
+STRESS_SCENARIOS = ("plain", "snp", "snp_sb", "snp_endcluster", "snp_primer", "snp_lowq", "biallelic",
+                    "het_ins", "het_del", "gap", "discord", "shallow", "empty", "allfail", "multi",
+                    "ndominant", "single")
+
+
+def stress_reference(seed=7):
+    """One chromosome with random sequence, homopolymer runs and a dinucleotide repeat."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    parts = []
+    for k in range(40):
+        parts.append("".join(rng.choice(list("ACGT"), size=60)))
+        if k % 4 == 1:
+            parts.append("A" * 12)
+        if k % 4 == 2:
+            parts.append("AC" * 14)
+        if k % 4 == 3:
+            parts.append("GGGGGGGGG")
+    return {"chrT": "".join(parts)}
+
+
+def generate_stress(n_loci: int, seed: int, scenarios=STRESS_SCENARIOS, chroms=None,
+                    max_umi: int = 60, deep: bool = False):
+    chroms = chroms or stress_reference()
+    seq = chroms["chrT"]
+    rng = np.random.Generator(np.random.PCG64([seed, n_loci]))
+    cols = {k: [] for k in ("umi", "frag", "flag", "mq", "nm", "n_indel", "left_sp", "qlen", "qalen",
+                            "qpos", "indel", "is_del", "allele", "bq")}
+    chrom, pos, ref, alleles, off = [], [], [], [], [0]
+    assert n_loci <= len(seq) - 60
+    positions = 30 + rng.permutation(len(seq) - 60)[:n_loci]    # distinct 1-based positions
+    for l in range(n_loci):
+        sc = scenarios[l % len(scenarios)]
+        p = int(positions[l])
+        r = seq[p - 1]
+        table = list(BASE_ALLELES)
+
+        def aid(s):
+            if s not in table:
+                table.append(s)
+            return table.index(s)
+
+        others = [c for c in "ATGC" if c != r]
+        alt = others[int(rng.integers(0, 3))]
+        alt2 = [c for c in others if c != alt][int(rng.integers(0, 2))]
+        ins_key = "INS|%s|%s%s" % (r, r, "".join(rng.choice(list("ACGT"), size=int(rng.integers(1, 4)))))
+        dlen = int(rng.integers(1, 4))
+        del_key = "DEL|%s%s|%s" % (r, seq[p:p + dlen], r)
+        U = int(rng.integers(1, max_umi + 1))
+        if sc == "shallow":
+            U = int(rng.integers(1, 5))
+        if sc == "empty":
+            U = 0
+        if sc == "single":
+            U = 1
+        if deep:
+            U = int(rng.integers(300, 900))
+        reads = []      # (umi_label, frag_label, dict)
+        for u in range(U):
+            nfr = int(rng.integers(1, 13)) if sc != "single" else 1
+            # true allele of this barcode
+            x = rng.random()
+            true = r
+            if sc in ("snp", "snp_sb", "snp_endcluster", "snp_primer", "snp_lowq") and x < 0.25:
+                true = alt
+            elif sc == "biallelic":
+                true = alt if x < 0.5 else alt2
+            elif sc == "het_ins" and x < 0.5:
+                true = ins_key
+            elif sc == "het_del" and x < 0.5:
+                true = del_key
+            elif sc == "gap" and x < 0.4:
+                true = "DEL"
+            elif sc == "ndominant" and x < 0.3:
+                true = "N"
+            elif sc == "multi":
+                true = [r, alt, alt2, ins_key, del_key, "DEL"][int(rng.integers(0, 6))]
+            for f in range(nfr):
+                y = rng.random()
+                nal = 1 if y < 0.45 else (2 if y < 0.93 else 3)
+                if sc == "discord":
+                    nal = 2
+                if sc == "single":
+                    nal = 1
+                for k in range(nal):
+                    a = true
+                    e = rng.random()
+                    perr = 0.45 if (sc == "discord" and k == 1) else 0.03
+                    if e < perr:
+                        a = ["A", "T", "G", "C", "N", "DEL", ins_key, del_key][int(rng.integers(0, 8))]
+                    is_r2 = (k % 2 == 1) if nal > 1 else bool(rng.random() < 0.5)
+                    rev = is_r2 ^ bool(rng.random() < 0.15)
+                    if sc == "snp_sb" and a == alt:
+                        rev = True
+                    if sc == "snp_sb" and a == r:
+                        rev = bool(rng.random() < 0.5)
+                    qlen = int(rng.integers(60, 151))
+                    lsp = int(rng.integers(1, 9)) if rng.random() < 0.1 else 0
+                    qalen = qlen - lsp - (int(rng.integers(1, 6)) if rng.random() < 0.1 else 0)
+                    qpos = lsp + int(rng.integers(0, qalen))
+                    if sc == "snp_endcluster" and a == alt:
+                        # put the variant near the barcode end: R1 fwd / R2 rev -> qpos small
+                        near = int(rng.integers(0, 15))
+                        far_side = (is_r2 and not rev) or ((not is_r2) and rev)
+                        qpos = lsp + (qalen - 1 - near if far_side else near)
+                    if sc == "snp_primer" and a == alt and is_r2:
+                        near = int(rng.integers(0, 3))
+                        qpos = lsp + (qalen - near if rev else near)
+                        qpos = min(qpos, lsp + qalen - 1) if not rev else qpos
+                    bqv = int(rng.choice([2, 10, 15, 19, 20, 21, 25, 30, 33, 37, 40, 41]))
+                    if sc == "snp_lowq" and a == alt and rng.random() < 0.6:
+                        bqv = int(rng.integers(2, 20))
+                    mqv = int(rng.choice([0, 10, 29, 30, 31, 60, 60, 60, 60, 60]))
+                    if sc == "allfail":
+                        mqv = int(rng.integers(0, 30))
+                    kind_ins = a.startswith("INS|")
+                    kind_dst = a.startswith("DEL|")
+                    is_gap = a == "DEL"
+                    n_ind = (len(a.split("|")[2]) - 1) if kind_ins else ((len(a.split("|")[1]) - 1) if kind_dst else (1 if is_gap else 0))
+                    mm = int(rng.choice([0, 0, 0, 1, 1, 2, 3, 5, 7, 9]))
+                    has_nm = rng.random() > 0.05
+                    fl = (F_READ2 if is_r2 else F_READ1)
+                    z = rng.random()
+                    if z < 0.03 and reads:
+                        fl = 0                              # neither flag: pairOrder carried over
+                    elif z < 0.05:
+                        fl = F_READ1 | F_READ2
+                    fl |= (F_REVERSE if rev else 0) | (F_HAS_NM if has_nm else 0)
+                    reads.append((u, f, dict(
+                        flag=fl, mq=mqv, nm=(mm + n_ind) if has_nm else 0, n_indel=n_ind, left_sp=lsp,
+                        qlen=qlen, qalen=qalen, qpos=qpos,
+                        indel=n_ind if kind_ins else (-n_ind if kind_dst else 0), is_del=is_gap,
+                        allele=aid(a), bq=bqv)))
+        perm = rng.permutation(len(reads))
+        # keep a flagged read first so the reference's pairOrder is defined (smCounter.py:359-381)
+        reads = [reads[i] for i in perm]
+        for i, rd in enumerate(reads):
+            if rd[2]["flag"] & (F_READ1 | F_READ2):
+                reads[0], reads[i] = reads[i], reads[0]
+                break
+        else:
+            if reads:
+                reads[0][2]["flag"] |= F_READ1
+        umap, fmap = {}, {}
+        for (u, f, d) in reads:
+            uu = umap.setdefault(u, len(umap))
+            fm = fmap.setdefault(uu, {})
+            ff = fm.setdefault(f, len(fm))
+            cols["umi"].append(uu)
+            cols["frag"].append(ff)
+            for k, v in d.items():
+                cols[k].append(v)
+        chrom.append("chrT")
+        pos.append(p)
+        ref.append(r)
+        alleles.append(table)
+        off.append(off[-1] + len(reads))
+    dt = dict(umi=np.uint32, frag=np.uint32, flag=np.uint8, mq=np.uint8, nm=np.uint32, n_indel=np.uint32,
+              left_sp=np.uint32, qlen=np.uint32, qalen=np.uint32, qpos=np.int32, indel=np.int32,
+              is_del=bool, allele=np.uint8, bq=np.uint8)
+    return PileupBatch(chrom=chrom, pos=np.array(pos, np.int64), ref=ref, alleles=alleles,
+                       read_off=np.array(off, np.int64),
+                       **{k: np.array(v, dt[k]) for k, v in cols.items()}), chroms

@@ -1,0 +1,56 @@
+"""Generate the golden input/output vectors under tests/golden/ (BUILD CONTAINER ONLY).
+
+Runs the reference implementation itself (/root/reference/smCounter.py, imported through
+oracle/ref_harness.py) on seeded synthetic pileups and stores, per fixture file:
+  inputs   - the primary pileup records (smcounter_amd.pileup.PileupBatch) + the fake FASTA,
+  params   - the numeric arguments passed to vc(),
+  expected - per locus: the exact string vc_wrapper() returned, the unrounded prediction indices
+             (PI_A, PI_T, PI_G, PI_C, PI_alt), every (table, oddsratio, pvalue) scipy's fisher_exact
+             produced, and whether the allele choice hinged on an unpinnable py2 dict tie.
+Usage:  PYTHONHASHSEED=0 python tests/golden/make_golden.py
+"""
+import dataclasses
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import ref_harness  # noqa: E402
+from smcounter_amd import pileup, synth  # noqa: E402
+from smcounter_amd.params import VcParams  # noqa: E402
+
+
+def emit(name, pb, params, chroms):
+    res = ref_harness.run_reference(pb, params, chroms)
+    assert not any(r["row"].startswith("Exception thrown!") for r in res), name
+    pileup.save_npz(os.path.join(HERE, name + ".npz"), pb, params=dataclasses.asdict(params),
+                    chroms=chroms, expected=res)
+    n_amb = sum(r["tie_ambiguous"] for r in res)
+    print("%-14s %4d loci %7d reads  %d tie-ambiguous" % (name, pb.n_loci, pb.n_reads, n_amb))
+
+
+def main():
+    stress = ((1, VcParams(mtDepth=200, rpb=8.6, hpLen=8, mtDrop=1), {}),
+              (2, VcParams(mtDepth=100, rpb=2.0, hpLen=6, mtDrop=0, primerDist=2), {}),
+              (3, VcParams(mtDepth=1000, rpb=1.2, hpLen=10, minBQ=25, minMQ=20, mismatchThr=4.0), {}),
+              (4, VcParams(mtDepth=1000, rpb=5, hpLen=8),
+               dict(deep=True, scenarios=("snp", "discord", "snp_sb", "het_ins", "biallelic",
+                                          "snp_endcluster"))))
+    for seed, params, kw in stress:
+        n = 12 if kw else 170
+        pb, chroms = synth.generate_stress(n, seed, **kw)
+        emit("stress%d" % seed, pb, params, chroms)
+    for name, n in (("C2", 64), ("C3", 6), ("C5", 3)):
+        cfg = synth.CONFIGS[name]
+        pb = synth.generate(cfg, 0, n)
+        # only the stretch of the periodic reference the loci can touch
+        lo = cfg.start_pos - 64
+        seq = "N" * lo + synth.CyclicRef().fetch(cfg.chrom, lo, cfg.start_pos + n + 64)
+        emit("synth_" + name, pb, synth.params_for(cfg), {cfg.chrom: seq})
+
+
+if __name__ == "__main__":
+    main()
