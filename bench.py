@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py - throughput of the per-locus hot path on synthetic pileups of stated depth.
+
+Metric (BASELINE.json): loci/s at fixed read-depth x reads-per-UMI.  Workload at every N:
+BASELINE.json configs[2] "synthetic 200k loci, 3000x depth, 50 UMIs/locus, 60 rpb" PER GPU (weak
+scaling: rank r calls loci [r*200k, (r+1)*200k) of the same seeded config), inputs resident in HBM
+before the timed region.  A step = one pass of the hot path (k_call_loci bins + k_filter_loci) over
+the rank's batch, followed, for N > 1, by the gather of the fixed-width rows to rank 0 (RCCL).
+
+Prints ONE JSON line on rank 0 (see the task contract): value = loci of all ranks / max-over-ranks
+time; roofline = algorithmic bytes (16 B/read + 360 B/locus) of the dominant kernel
+over its mean HIP-event duration, against 8 TB/s; cpu_baseline = the C restatement under oracle/
+timed on one host core on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from smcounter_amd import abi, engine, synth  # noqa: E402
+from smcounter_amd import dist as smcdist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C3", help="synthetic config (C2, C3, C5); C3 is the metric's")
+    ap.add_argument("--loci-per-gpu", type=int, default=0, help="override (default: the config's size)")
+    ap.add_argument("--chunk", type=int, default=25000, help="loci generated/uploaded per chunk")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)"
+                         % (a.gpus, world))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = synth.CONFIGS[a.config]
+    params = synth.params_for(cfg)
+    n_loc = a.loci_per_gpu or cfg.n_loci
+    lo, hi = smcdist.shard_range(n_loc * world, rank, world)      # contiguous, equal (weak scaling)
+    eng = engine.Engine(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    # ---- build the rank's batch in HBM, chunk by chunk (host RAM stays bounded)
+    t0 = time.time()
+    stride = (cfg.depth + 3) // 4 * 4
+    planes = [torch.empty(n_loc * stride, dtype=torch.int32, device=dev) for _ in range(4)]
+    loci_parts, sample = [], None
+    nthreads = max(1, (os.cpu_count() or 1) // max(1, world))
+    for c0 in range(lo, hi, a.chunk):
+        c1 = min(hi, c0 + a.chunk)
+        db = synth.generate_native(cfg, c0, c1, params, nthreads=nthreads)
+        off = (c0 - lo) * stride
+        for pl, src in zip(planes, (db.meta, db.umi, db.frag, db.dist)):
+            pl[off:off + db.n_slots].copy_(torch.from_numpy(src.view(np.int32)))
+        loc = db.loci.copy()
+        loc["read_off"] += off
+        loci_parts.append(loc)
+        if sample is None:
+            sample = db                                           # kept for the CPU leg / parity check
+    loci = np.concatenate(loci_parts)
+    plan = eng.make_plan(loci)
+    rows = plan.alloc_rows()
+    torch.cuda.synchronize()
+    t_build = time.time() - t0
+
+    gather_buf = None
+    if world > 1 and rank == 0:
+        gather_buf = [torch.empty_like(rows) for _ in range(world)]
+
+    def step():
+        plan.run(planes, params, rows)
+        if world > 1:
+            smcdist.gather_rows(rows, gather_buf, dst=0)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    plan.set_timing(min(a.steps, 64))
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    k_ms, k_n, k_loci, k_reads = plan.kernel_ms()
+    plan.set_timing(0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    out = None
+    if rank == 0:
+        total_loci = n_loc * world
+        ms_per_step = elapsed / a.steps * 1e3
+        alg_bytes = 16.0 * k_reads + 360.0 * k_loci              # per launch of the dominant kernel
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("%s:%d" % (a.config, n_loc))
+        out = {
+            "metric": "loci/sec at fixed read-depth x rpb", "value": total_loci * a.steps / elapsed,
+            "unit": "loci/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8/u32 scan + f64 posterior", "data": "synthetic",
+            "config": {"workload": "%s: %d loci/GPU x %d reads (%d UMIs x %d rpb), seed %d"
+                       % (cfg.name, n_loc, cfg.depth, cfg.n_umi, cfg.rpb, cfg.seed),
+                       "loci_total": total_loci, "parallelism": "loci sharded x%d, rows gathered to rank 0" % world,
+                       "build_s": round(t_build, 1)},
+            "roofline": {"bound": "hbm", "kernel": "k_call_loci", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel_ms": k_ms, "kernel_samples": k_n, "loci_per_launch": k_loci,
+                         "alg_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"], out["parity_sample"] = cpu_leg(sample, params, plan, rows)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_leg(sample, params, plan, rows):
+    """The C restatement (oracle/) on one host core over the first chunk of the same workload, and a
+    field-by-field check of the GPU rows of that chunk against it."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_lib
+    n = sample.n_loci
+    t = time.perf_counter()
+    ref_rows = oracle_lib.call_batch(sample, abi.c_params(params), abi.ROW_DTYPE)
+    dt = time.perf_counter() - t
+    gpu_rows = plan.download(rows)[:n]
+    bad = abi.compare_rows(gpu_rows, ref_rows)
+    base = {"value": n / dt, "unit": "loci/s", "cores": 1, "kind": "port",
+            "sample": "first %d loci of the same workload, C restatement oracle/smc_oracle.c, 1 thread, %.1f s"
+                      % (n, dt)}
+    return base, {"loci": n, "mismatches": len(bad), "detail": bad[:3]}
+
+
+if __name__ == "__main__":
+    main()

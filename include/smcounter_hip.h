@@ -158,6 +158,13 @@ void smc_plan_destroy(smc_plan* plan);
 /* number of kernel launches one smc_plan_run issues, and bytes of device scratch it holds */
 int smc_plan_info(const smc_plan* plan, int32_t* n_launches, int64_t* scratch_bytes);
 
+/* Optional: bracket the dominant k_call_loci launch (the bin holding most reads) of each
+ * smc_plan_run with a HIP event pair on the run's stream, kept in a ring of `slots` pairs
+ * (0 disables). smc_plan_kernel_ms synchronises on the recorded pairs and returns that launch's
+ * mean duration over the last min(runs, slots) runs, with the loci and reads one launch covers. */
+int smc_plan_set_timing(smc_plan* plan, int slots);
+int smc_plan_kernel_ms(smc_plan* plan, float* avg_ms, int32_t* n_samples, int64_t* n_loci, int64_t* n_reads);
+
 /* Run the hot path over the batch. meta/umi/frag/dist and rows are DEVICE pointers
  * (n_slots x uint32 each; rows n_loci x smc_row). `stream` is a hipStream_t (NULL = default
  * stream). Asynchronous: returns after enqueueing. */

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(HERE, "libsmcounter_hip.so")
 
 SYMBOLS = ("smc_abi_version", "smc_last_error", "smc_row_size", "smc_locus_size", "smc_device_count",
            "smc_create", "smc_destroy", "smc_plan_create", "smc_plan_destroy", "smc_plan_info",
-           "smc_plan_run", "smc_call_batch_host", "smc_event_create", "smc_event_record",
+           "smc_plan_run", "smc_plan_set_timing", "smc_plan_kernel_ms", "smc_call_batch_host", "smc_event_create", "smc_event_record",
            "smc_event_elapsed_ms", "smc_event_destroy")
 
 
@@ -45,6 +45,9 @@ def load():
     L.smc_plan_destroy.restype = None
     L.smc_plan_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i64)]
     L.smc_plan_run.argtypes = [vp, ctypes.POINTER(abi.SmcParams), vp, vp, vp, vp, vp, vp]
+    L.smc_plan_set_timing.argtypes = [vp, ctypes.c_int]
+    L.smc_plan_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(i32), ctypes.POINTER(i64),
+                                     ctypes.POINTER(i64)]
     L.smc_call_batch_host.argtypes = [vp, ctypes.POINTER(abi.SmcParams), vp, i64, vp, vp, vp, vp, i64, vp]
     L.smc_event_create.argtypes = [ctypes.POINTER(vp)]
     L.smc_event_record.argtypes = [vp, vp]

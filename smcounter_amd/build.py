@@ -35,5 +35,20 @@ def build_hip(force: bool = False, extra_flags=()) -> str:
     return LIB
 
 
+SYNTH_SRC = os.path.join(HERE, "csrc", "smc_synth.cpp")
+SYNTH_LIB = os.path.join(HERE, "libsmc_synth.so")
+
+
+def build_synth(force: bool = False) -> str:
+    """Host-side workload generator (plain g++)."""
+    hdr = os.path.join(ROOT, "include", "smcounter_hip.h")
+    if force or not os.path.exists(SYNTH_LIB) or \
+            max(os.path.getmtime(SYNTH_SRC), os.path.getmtime(hdr)) > os.path.getmtime(SYNTH_LIB):
+        subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-pthread",
+                               "-I" + os.path.join(ROOT, "include"), "-o", SYNTH_LIB, SYNTH_SRC])
+    return SYNTH_LIB
+
+
 if __name__ == "__main__":
     print(build_hip(force=True))
+    print(build_synth(force=True))

@@ -1,0 +1,209 @@
+// smc_synth.cpp - fast host-side generator of the synthetic pileup workloads (SURVEY.md 8d /
+// BASELINE.json configs C2-C5), multithreaded, writing the HBM structure-of-arrays layout directly.
+//
+// Same workload definition as smcounter_amd/synth.py::generate (which stays the readable reference
+// and the source of the golden fixtures): per locus `n_umi` barcodes x `rpb` reads, fragments with
+// a fraction p_overlap of mate pairs, random interleave, ids relabelled by first appearance, ref
+// base "ACGT"[pos % 4], per-read error / in-deletion / insertion-start / deletion-start events, the
+// fixed small distributions for quality, MAPQ, mismatches, lengths, soft clips and positions, and the
+// per-read feature arithmetic of smCounter.py:352-356 / :432-452.  Each locus draws from its own
+// counter-seeded stream (seed, locus index), so output does not depend on the thread count.
+//
+// Used by bench.py and the large-size tests to build inputs; not on the calling path.
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <thread>
+#include <vector>
+
+#include "smcounter_hip.h"
+
+namespace {
+
+struct Rng {   // xoshiro256** seeded by splitmix64
+    uint64_t s[4];
+    static uint64_t sm(uint64_t& x) {
+        uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    Rng(uint64_t seed, uint64_t stream) {
+        uint64_t x = seed * 0xD1342543DE82EF95ull + stream;
+        for (auto& v : s) v = sm(x);
+    }
+    static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+    uint64_t next() {
+        const uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45);
+        return r;
+    }
+    double uni() { return (next() >> 11) * (1.0 / 9007199254740992.0); }
+    uint32_t below(uint32_t n) { return (uint32_t)(((next() >> 32) * (uint64_t)n) >> 32); }
+};
+
+struct Rd {
+    uint32_t umi, frag;
+    uint8_t allele, bq, mq, flags;   // flags: device flag byte
+    uint16_t dbc, dpr;
+};
+
+}  // namespace
+
+extern "C" {
+
+typedef struct smc_synth_cfg {
+    int64_t n_loci_total;
+    int32_t n_umi, rpb;
+    uint64_t seed;
+    int64_t start_pos;
+    double p_overlap, p_err, p_gap, p_ins, p_delstart, p_n, alt_locus_frac, alt_af;
+    double mismatch_thr;
+} smc_synth_cfg;
+
+// slots needed for loci [lo,hi): every locus padded to a multiple of 4 reads
+int64_t smc_synth_slots(const smc_synth_cfg* c, int64_t lo, int64_t hi) {
+    const int64_t r = (int64_t)c->n_umi * c->rpb;
+    return (hi - lo) * ((r + 3) / 4 * 4);
+}
+
+// extra[l]: bit0 insertion allele present, bit1 deletion-start allele present, bit2 insertion got
+// the lower id (6).  Strings are rebuilt on the host from pos (smcounter_amd/synth.py).
+int smc_synth_generate(const smc_synth_cfg* c, int64_t lo, int64_t hi, uint32_t* meta, uint32_t* umi, uint32_t* frag,
+                       uint32_t* dist, smc_locus* loci, uint8_t* extra, int nthreads) {
+    const int U = c->n_umi, B = c->rpb, R = U * B;
+    const int64_t stride = (R + 3) / 4 * 4;
+    const int f0 = std::max(1, (int)llround(B / (1.0 + c->p_overlap)));
+    static const uint8_t ref_by_mod[4] = {0, 3, 2, 1};   // "ACGT"[p%4] -> allele id (A0 T1 G2 C3)
+    static const uint8_t trans[4] = {2, 3, 0, 1};        // A<->G, T<->C
+    static const uint8_t bqv[5] = {12, 25, 30, 37, 40};
+    static const double bqc[5] = {.03, .10, .30, .70, 1.0};
+    auto work = [&](int64_t a, int64_t b) {
+        std::vector<Rd> rd(R), out(R);
+        std::vector<int> perm(R), ufirst(U), urank(U), forig(R), kp(U);
+        std::vector<int> ffirst, frank;
+        for (int64_t l = a; l < b; ++l) {
+            Rng g(c->seed, (uint64_t)l);
+            const int64_t pos = c->start_pos + l;
+            const int ref = ref_by_mod[pos & 3];
+            const bool alt_locus = c->alt_locus_frac > 0 && g.uni() < c->alt_locus_frac;
+            int n_frag_total = 0;
+            int idx = 0;
+            for (int u = 0; u < U; ++u) {
+                int k = 0;
+                for (int t = 0; t < f0; ++t) k += g.uni() < c->p_overlap;
+                k = std::min(k, B / 2);
+                kp[u] = k;
+                n_frag_total += B - k;
+                int tru = ref;
+                if (alt_locus && g.uni() < c->alt_af) tru = trans[ref];
+                for (int j = 0; j < B; ++j, ++idx) {
+                    Rd& r = rd[idx];
+                    const bool in_pair = j < 2 * k;
+                    forig[idx] = in_pair ? j / 2 : j - k;
+                    const bool r2 = in_pair ? (j & 1) : (g.uni() < 0.5);
+                    const bool rev = r2 ^ (g.uni() < 0.1);
+                    int al = tru;
+                    if (g.uni() < c->p_err) al = (al + 1 + (int)g.below(3)) & 3;
+                    const bool carries_alt = al != ref;
+                    const double ev = g.uni();
+                    int kind = SMC_KIND_BASE;
+                    bool is_n = false;
+                    if (ev < c->p_gap) { kind = SMC_KIND_GAP; al = 5; }
+                    else if (ev < c->p_gap + c->p_ins) { kind = SMC_KIND_INS; al = 254; }
+                    else if (ev < c->p_gap + c->p_ins + c->p_delstart) { kind = SMC_KIND_DELSTART; al = 253; }
+                    else if (ev >= 1.0 - c->p_n) { is_n = true; al = 4; }
+                    const double qx = g.uni();
+                    int qi = 0;
+                    while (qx >= bqc[qi]) ++qi;
+                    const int mq = g.uni() < 0.02 ? 20 : 60;
+                    const double mx = g.uni();
+                    int mism = mx < .8 ? 0 : (mx < .95 ? 1 : 2);
+                    if (carries_alt && kind == SMC_KIND_BASE && !is_n) mism += 1;
+                    if (g.uni() < 0.01) mism = 8;
+                    const int qlen = 100 + (int)g.below(51);
+                    const int lsp = g.uni() < 0.05 ? 1 + (int)g.below(10) : 0;
+                    const int qalen = qlen - lsp;
+                    const int qpos = lsp + (int)(g.uni() * qalen);
+                    // features (smCounter.py:352-356, :432-452)
+                    const double mm100 = 100.0 * mism / qlen;
+                    const bool mm_ok = mm100 <= c->mismatch_thr;
+                    const int rel = qpos - lsp, far = qalen - rel;
+                    int dbc = 0, dpr = 0;
+                    if (kind == SMC_KIND_BASE) {
+                        dbc = r2 ? (rev ? rel : far) : (rev ? far : rel);
+                        dpr = r2 ? (rev ? far : rel) : 0;
+                    }
+                    r.umi = (uint32_t)u;
+                    r.frag = 0;
+                    r.allele = (uint8_t)al;
+                    r.bq = bqv[qi];
+                    r.mq = (uint8_t)mq;
+                    r.flags = (uint8_t)((r2 ? SMC_FL_R2 : 0) | (rev ? SMC_FL_REV : 0) | (mm_ok ? SMC_FL_MMOK : 0) |
+                                        (kind << SMC_KIND_SHIFT));
+                    r.dbc = (uint16_t)std::min(dbc, 65535);
+                    r.dpr = (uint16_t)std::min(dpr, 65535);
+                }
+            }
+            // random interleave (Fisher-Yates)
+            for (int i = 0; i < R; ++i) perm[i] = i;
+            for (int i = R - 1; i > 0; --i) std::swap(perm[i], perm[g.below((uint32_t)i + 1)]);
+            // relabel by first appearance
+            std::fill(ufirst.begin(), ufirst.end(), -1);
+            ffirst.assign(R, -1);   // indexed u*B + original fragment
+            int nu = 0;
+            std::vector<int> fcount(U, 0);
+            int first_ins = R + 1, first_dst = R + 1;
+            for (int i = 0; i < R; ++i) {
+                const int src = perm[i];
+                Rd r = rd[src];
+                const int u = (int)r.umi;
+                if (ufirst[u] < 0) ufirst[u] = nu++;
+                int& ff = ffirst[u * B + forig[src]];
+                if (ff < 0) ff = fcount[u]++;
+                r.umi = (uint32_t)ufirst[u];
+                r.frag = (uint32_t)ff;
+                if (r.allele == 254 && first_ins > R) first_ins = i;
+                if (r.allele == 253 && first_dst > R) first_dst = i;
+                out[i] = r;
+            }
+            const int ins_id = first_ins < first_dst ? 6 : 7;
+            const int dst_id = first_dst < first_ins ? 6 : (first_ins <= R ? 7 : 6);
+            const int64_t off = (l - lo) * stride;
+            for (int i = 0; i < R; ++i) {
+                Rd& r = out[i];
+                int al = r.allele;
+                if (al == 254) al = ins_id; else if (al == 253) al = dst_id;
+                meta[off + i] = (uint32_t)al | ((uint32_t)r.bq << 8) | ((uint32_t)r.flags << 16) | ((uint32_t)r.mq << 24);
+                umi[off + i] = r.umi;
+                frag[off + i] = r.frag;
+                dist[off + i] = (uint32_t)r.dbc | ((uint32_t)r.dpr << 16);
+            }
+            for (int64_t i = R; i < stride; ++i) meta[off + i] = umi[off + i] = frag[off + i] = dist[off + i] = 0;
+            smc_locus& L = loci[l - lo];
+            L.read_off = off;
+            L.n_reads = R;
+            L.n_umi = U;
+            L.n_frag = n_frag_total;
+            L.ref_allele = (uint8_t)ref;
+            const int n_extra = (first_ins <= R) + (first_dst <= R);
+            L.n_alleles = (uint8_t)(6 + n_extra);
+            L.flags = 0;
+            L.snp_mask = 0x1F;
+            extra[l - lo] = (uint8_t)((first_ins <= R ? 1 : 0) | (first_dst <= R ? 2 : 0) | (first_ins < first_dst ? 4 : 0));
+        }
+    };
+    nthreads = std::max(1, nthreads);
+    std::vector<std::thread> th;
+    const int64_t n = hi - lo, per = (n + nthreads - 1) / nthreads;
+    for (int t = 0; t < nthreads; ++t) {
+        const int64_t a = lo + t * per, b = std::min(hi, a + per);
+        if (a < b) th.emplace_back(work, a, b);
+    }
+    for (auto& t : th) t.join();
+    return 0;
+}
+
+}  // extern "C"

@@ -880,6 +880,11 @@ struct smc_plan {
     int64_t n_loci;
     smc_locus* d_loci = nullptr;
     std::vector<Bin> bins;
+    // optional HIP-event timing of the dominant k_call_loci launch (the bin with most reads)
+    int timing = 0, dom_bin = -1;
+    int64_t dom_loci = 0, dom_reads = 0;
+    std::vector<hipEvent_t> ev0, ev1;   // ring of event pairs, one per timed run
+    int64_t n_timed = 0;
 };
 
 template <int BLOCK, bool GT>
@@ -940,6 +945,8 @@ void smc_plan_destroy(smc_plan* p) {
     if (!p) return;
     (void)hipSetDevice(p->ctx->device);
     (void)hipFree(p->d_loci);
+    for (auto e : p->ev0) (void)hipEventDestroy(e);
+    for (auto e : p->ev1) (void)hipEventDestroy(e);
     for (auto& b : p->bins) {
         (void)hipFree(b.d_order);
         (void)hipFree(b.d_scratch_off);
@@ -999,11 +1006,46 @@ int smc_plan_create(smc_ctx* ctx, const smc_locus* loci, int64_t n_loci, smc_pla
             HIPCHK(hipMemcpy(b.d_scratch_off, soff.data(), sizeof(int64_t) * soff.size(), hipMemcpyHostToDevice));
             HIPCHK(hipMalloc(&b.d_scratch, b.scratch_bytes));
         }
+        int64_t reads = 0;
+        for (int l : b.order) reads += loci[l].n_reads;
+        if (reads > p->dom_reads) { p->dom_reads = reads; p->dom_loci = (int64_t)b.order.size(); p->dom_bin = (int)p->bins.size(); }
         p->bins.push_back(b);
     }
     *out = p;
     return SMC_OK;
 }
+
+int smc_plan_set_timing(smc_plan* p, int slots) {
+    if (!p || slots < 0) return fail(SMC_E_ARG, "smc_plan_set_timing: bad argument");
+    HIPCHK(hipSetDevice(p->ctx->device));
+    for (auto e : p->ev0) (void)hipEventDestroy(e);
+    for (auto e : p->ev1) (void)hipEventDestroy(e);
+    p->ev0.assign((size_t)slots, nullptr);
+    p->ev1.assign((size_t)slots, nullptr);
+    for (int k = 0; k < slots; ++k) { HIPCHK(hipEventCreate(&p->ev0[k])); HIPCHK(hipEventCreate(&p->ev1[k])); }
+    p->timing = slots;
+    p->n_timed = 0;
+    return SMC_OK;
+}
+
+int smc_plan_kernel_ms(smc_plan* p, float* avg_ms, int32_t* n_samples, int64_t* n_loci, int64_t* n_reads) {
+    if (!p || !avg_ms) return fail(SMC_E_ARG, "smc_plan_kernel_ms: NULL argument");
+    const int64_t ns = p->n_timed < p->timing ? p->n_timed : p->timing;
+    if (ns <= 0) return fail(SMC_E_ARG, "smc_plan_kernel_ms: no timed run (smc_plan_set_timing(plan, slots) then smc_plan_run)");
+    double tot = 0;
+    for (int64_t k = 0; k < ns; ++k) {
+        float ms = 0;
+        HIPCHK(hipEventSynchronize(p->ev1[k]));
+        HIPCHK(hipEventElapsedTime(&ms, p->ev0[k], p->ev1[k]));
+        tot += ms;
+    }
+    *avg_ms = (float)(tot / ns);
+    if (n_samples) *n_samples = (int32_t)ns;
+    if (n_loci) *n_loci = p->dom_loci;
+    if (n_reads) *n_reads = p->dom_reads;
+    return SMC_OK;
+}
+
 
 int smc_plan_info(const smc_plan* p, int32_t* n_launches, int64_t* scratch_bytes) {
     if (!p) return fail(SMC_E_ARG, "smc_plan_info: NULL plan");
@@ -1024,7 +1066,11 @@ int smc_plan_run(smc_plan* p, const smc_params* prm, const uint32_t* meta, const
     HIPCHK(hipSetDevice(p->ctx->device));
     hipStream_t st = (hipStream_t)stream;
     KParams kp{prm->min_bq, prm->min_mq, prm->mt_drop, prm->primer_dist, prm->ds, prm->smt};
-    for (const Bin& b : p->bins) {
+    for (size_t bi = 0; bi < p->bins.size(); ++bi) {
+        const Bin& b = p->bins[bi];
+        const bool timed = p->timing > 0 && (int)bi == p->dom_bin;
+        const size_t slot = timed ? (size_t)(p->n_timed % p->timing) : 0;
+        if (timed) HIPCHK(hipEventRecord(p->ev0[slot], st));
         hipError_t e = hipSuccess;
         switch (b.cls) {
             case 0: e = launch_bin<64, false>(b, kp, p, meta, umi, frag, dist, rows, st); break;
@@ -1034,6 +1080,7 @@ int smc_plan_run(smc_plan* p, const smc_params* prm, const uint32_t* meta, const
             default: e = launch_bin<1024, true>(b, kp, p, meta, umi, frag, dist, rows, st); break;
         }
         if (e != hipSuccess) return fail(SMC_E_HIP, std::string("k_call_loci launch: ") + hipGetErrorString(e));
+        if (timed) { HIPCHK(hipEventRecord(p->ev1[slot], st)); p->n_timed++; }
     }
     hipLaunchKernelGGL(k_filter_loci, dim3((unsigned)p->n_loci), dim3(WAVE), 0, st, kp, p->d_loci, rows, (int)p->n_loci);
     hipError_t e = hipGetLastError();

@@ -1,0 +1,60 @@
+"""Multi-GPU sharding of the locus list and the row gather.
+
+The reference's only parallelism is a process pool over loci with results collected in
+submission order (smCounter.py:683-685).  Loci share nothing, so here rank r of N calls a
+contiguous range of the ordered locus list on its own GPU and the fixed-width rows
+(include/smcounter_hip.h: smc_row) are gathered to rank 0 in rank order, which restores the
+submission order.  One collective per batch: a gather (variable block sizes are padded to the
+largest block; RCCL has no gatherv).  Works with the `nccl` (= RCCL) backend on GPUs and with
+`gloo` on CPU tensors (used by the tests).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+
+def shard_range(n_loci: int, rank: int, world: int):
+    """Contiguous, near-equal split by locus count."""
+    base, rem = divmod(n_loci, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_by_reads(n_reads: Sequence[int], world: int) -> List[int]:
+    """Contiguous split balanced by the number of pileup reads (depth varies several-fold across a
+    real panel).  Returns world+1 boundaries into the locus list."""
+    c = np.concatenate([[0], np.cumsum(np.asarray(n_reads, np.int64))])
+    total = int(c[-1])
+    cuts = [0]
+    for r in range(1, world):
+        cuts.append(int(np.searchsorted(c, total * r / world, side="left")))
+    cuts.append(len(n_reads))
+    for i in range(1, len(cuts)):
+        cuts[i] = max(cuts[i], cuts[i - 1])
+    return cuts
+
+
+def gather_rows(rows, gather_list: Optional[list], dst: int = 0):
+    """Equal-size gather of a rank's row bytes to `dst` (weak-scaling bench path)."""
+    import torch.distributed as dist
+    dist.gather(rows, gather_list if dist.get_rank() == dst else None, dst=dst)
+
+
+def gatherv_rows(rows, counts: Sequence[int], row_bytes: int, dst: int = 0):
+    """Variable-size gather: every rank pads its block to max(counts) rows; `dst` returns the
+    concatenation in rank order (a uint8 tensor), other ranks return None."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    mx = max(counts) * row_bytes
+    buf = rows
+    if rows.numel() < mx:
+        buf = torch.zeros(mx, dtype=rows.dtype, device=rows.device)
+        buf[:rows.numel()] = rows
+    glist = [torch.empty(mx, dtype=rows.dtype, device=rows.device) for _ in range(world)] if rank == dst else None
+    dist.gather(buf, glist, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([g[:counts[r] * row_bytes] for r, g in enumerate(glist)])

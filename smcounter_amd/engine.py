@@ -83,6 +83,17 @@ class Plan(object):
                                            ctypes.c_void_p(st.cuda_stream)), "smc_plan_run")
         return rows
 
+    def set_timing(self, slots: int):
+        """Keep HIP-event pairs around the dominant kernel of the next `slots` runs (0 = off)."""
+        _lib.check(self.eng.L.smc_plan_set_timing(self.h, int(slots)), "smc_plan_set_timing")
+
+    def kernel_ms(self):
+        """(mean ms, samples, loci, reads) of the dominant k_call_loci launch over the timed runs."""
+        ms, ns, nl, nr = ctypes.c_float(), ctypes.c_int32(), ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(self.eng.L.smc_plan_kernel_ms(self.h, ctypes.byref(ms), ctypes.byref(ns), ctypes.byref(nl),
+                                                 ctypes.byref(nr)), "smc_plan_kernel_ms")
+        return ms.value, ns.value, nl.value, nr.value
+
     @staticmethod
     def download(rows) -> np.ndarray:
         return rows.cpu().numpy().view(abi.ROW_DTYPE)

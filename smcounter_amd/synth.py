@@ -403,3 +403,57 @@ def generate_stress(n_loci: int, seed: int, scenarios=STRESS_SCENARIOS, chroms=N
     return PileupBatch(chrom=chrom, pos=np.array(pos, np.int64), ref=ref, alleles=alleles,
                        read_off=np.array(off, np.int64),
                        **{k: np.array(v, dt[k]) for k, v in cols.items()}), chroms
+
+
+# ---------------------------------------------------------------------------------------------
+# Native generator (smcounter_amd/csrc/smc_synth.cpp): same workload definition, written straight
+# into the HBM layout by a thread pool; used for the full-size configs.
+# ---------------------------------------------------------------------------------------------
+def generate_native(cfg: SynthConfig, lo: int = 0, hi: int = None, params=None, nthreads: int = 0):
+    """-> smcounter_amd.features.DeviceBatch for loci [lo, hi) of `cfg`."""
+    import ctypes
+    import os
+    from . import build
+    from .features import DeviceBatch, LOCUS_DTYPE
+
+    class Cfg(ctypes.Structure):
+        _fields_ = [("n_loci_total", ctypes.c_int64), ("n_umi", ctypes.c_int32), ("rpb", ctypes.c_int32),
+                    ("seed", ctypes.c_uint64), ("start_pos", ctypes.c_int64),
+                    ("p_overlap", ctypes.c_double), ("p_err", ctypes.c_double), ("p_gap", ctypes.c_double),
+                    ("p_ins", ctypes.c_double), ("p_delstart", ctypes.c_double), ("p_n", ctypes.c_double),
+                    ("alt_locus_frac", ctypes.c_double), ("alt_af", ctypes.c_double),
+                    ("mismatch_thr", ctypes.c_double)]
+
+    hi = cfg.n_loci if hi is None else hi
+    params = params or params_for(cfg)
+    lib = ctypes.CDLL(build.build_synth())
+    lib.smc_synth_slots.restype = ctypes.c_int64
+    c = Cfg(cfg.n_loci, cfg.n_umi, cfg.rpb, cfg.seed, cfg.start_pos, cfg.p_overlap, cfg.p_err, cfg.p_gap,
+            cfg.p_ins, cfg.p_delstart, cfg.p_n, cfg.alt_locus_frac, cfg.alt_af, params.mismatchThr)
+    n = hi - lo
+    slots = lib.smc_synth_slots(ctypes.byref(c), ctypes.c_int64(lo), ctypes.c_int64(hi))
+    planes = [np.empty(slots, np.uint32) for _ in range(4)]
+    loci = np.zeros(n, LOCUS_DTYPE)
+    extra = np.zeros(n, np.uint8)
+    nthreads = nthreads or min(32, os.cpu_count() or 1)
+    rc = lib.smc_synth_generate(ctypes.byref(c), ctypes.c_int64(lo), ctypes.c_int64(hi),
+                                *[p.ctypes.data_as(ctypes.c_void_p) for p in planes],
+                                loci.ctypes.data_as(ctypes.c_void_p), extra.ctypes.data_as(ctypes.c_void_p),
+                                ctypes.c_int(nthreads))
+    assert rc == 0
+    pos = cfg.start_pos + np.arange(lo, hi, dtype=np.int64)
+    ref = _ID_TO_LETTER[_REF_ID_BY_PMOD4[pos % 4]].tolist()
+    base = list(BASE_ALLELES)
+    alleles = [base] * n
+    for l in np.nonzero(extra)[0].tolist():
+        r, p, e = ref[l], int(pos[l]), int(extra[l])
+        ins_s = "INS|%s|%s%s" % (r, r, _LETTERS[(p + 2) % 4])
+        del_s = "DEL|%s%s|%s" % (r, _LETTERS[(p + 1) % 4], r)
+        if (e & 3) == 3:
+            alleles[l] = base + ([ins_s, del_s] if e & 4 else [del_s, ins_s])
+        elif e & 1:
+            alleles[l] = base + [ins_s]
+        else:
+            alleles[l] = base + [del_s]
+    return DeviceBatch(loci=loci, meta=planes[0], umi=planes[1], frag=planes[2], dist=planes[3],
+                       chrom=[cfg.chrom] * n, pos=pos, ref=ref, alleles=alleles)

@@ -1,0 +1,135 @@
+"""Parity of the HIP path (through the C ABI) against the CPU restatement and the reference's golden
+vectors.  Integer columns bit-exact; PI and Fisher p-values within 1e-6 (BASELINE.json)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden_files, load_golden
+from smcounter_amd import abi, features, pileup, rows, synth
+from smcounter_amd.params import VcParams
+
+import oracle_lib
+
+pytestmark = pytest.mark.gpu
+PI_TOL = 1e-6
+P_TOL = 1e-6
+
+
+@pytest.mark.parametrize("path", golden_files(), ids=os.path.basename)
+def test_golden_rows_vs_oracle_and_reference(engine0, path):
+    pb, db, P, refp, expected = load_golden(path)
+    got = engine0.call_batch_host(db, P)
+    want = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE)
+    assert abi.compare_rows(got, want, PI_TOL, P_TOL) == []
+    text = rows.format_rows(got, db, P, refp)
+    ties = abi.near_tie_loci(got, want)
+    for l, (t, e) in enumerate(zip(text, expected)):
+        if e["tie_ambiguous"] or l in ties:
+            continue
+        assert t == e["row"], "locus %d differs from the reference's own output" % l
+        if e["pi_raw"]:
+            d = max(max(abs(e["pi_raw"][k] - got["pi"][l][k]) for k in range(4)),
+                    abs(e["pi_raw"][4] - got["cand"][l][0]["pi"]))
+            assert d <= PI_TOL
+
+
+@pytest.mark.parametrize("name,n", [("C2", 3000), ("C3", 1500), ("C5", 300)])
+def test_synthetic_configs_vs_oracle(engine0, name, n):
+    cfg = synth.CONFIGS[name]
+    P = synth.params_for(cfg)
+    db = synth.generate_native(cfg, 0, n, P)
+    planes = engine0.upload(db)
+    plan = engine0.make_plan(db.loci)
+    got = plan.download(plan.run(planes, P))
+    want = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE)
+    assert abi.compare_rows(got, want, PI_TOL, P_TOL) == []
+    assert float(np.abs(got["pi"] - want["pi"]).max()) <= PI_TOL
+    # run-to-run bit reproducibility (fixed-point PI accumulation, no float atomics)
+    again = plan.download(plan.run(planes, P))
+    assert again.tobytes() == got.tobytes()
+    plan.close()
+
+
+def test_stress_mix_of_sizes_and_bins(engine0):
+    """Loci of very different sizes in one batch: exercises every launch bin, including the
+    global-scratch one, and the zero-coverage / tiny loci."""
+    parts = []
+    a, _ = synth.generate_stress(120, 21)
+    b, _ = synth.generate_stress(6, 22, deep=True, scenarios=("snp", "discord", "multi", "biallelic"))
+    c, _ = synth.generate_stress(2, 23, deep=True, max_umi=60, scenarios=("snp",))
+    pb = pileup.concat([a, b, c])
+    P = VcParams(mtDepth=5000, rpb=3.0, hpLen=8, mtDrop=1)
+    db = features.extract_features(pb, P)
+    got = engine0.call_batch_host(db, P)
+    want = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE)
+    assert abi.compare_rows(got, want, PI_TOL, P_TOL) == []
+
+
+def test_huge_locus_uses_global_tables(engine0):
+    """One locus too large for LDS tables (> 160 KB): the global-scratch bin."""
+    cfg = synth.SynthConfig("big", 2, 3000, 12, 99)
+    P = synth.params_for(cfg)
+    db = synth.generate_native(cfg, 0, 2, P)
+    assert 8 * int(db.loci["n_frag"][0]) > 160 * 1024
+    got = engine0.call_batch_host(db, P)
+    want = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE)
+    assert abi.compare_rows(got, want, PI_TOL, P_TOL) == []
+
+
+def test_triple_alignment_fragments(engine0):
+    """Read names with >= 3 included alignments on one locus (re-created fragments,
+    smCounter.py:468-479): the sequential replay path."""
+    pb, chroms = synth.generate_stress(40, 31, scenarios=("multi", "discord", "snp"))
+    P = VcParams(mtDepth=500, rpb=4.0, hpLen=8, minBQ=2, minMQ=0, mismatchThr=100.0)
+    db = features.extract_features(pb, P)
+    got = engine0.call_batch_host(db, P)
+    want = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE)
+    assert abi.compare_rows(got, want, PI_TOL, P_TOL) == []
+
+
+def test_downsample_flag_and_empty_batch(engine0):
+    cfg = synth.CONFIGS["C2"]
+    P = VcParams(minBQ=20, minMQ=30, mtDepth=5, rpb=10.0, hpLen=8)       # ds = 10 < 30 barcodes
+    db = synth.generate_native(cfg, 0, 16, P)
+    got = engine0.call_batch_host(db, P)
+    want = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE)
+    assert (got["status"] & abi.ST_DOWNSAMPLED).all()
+    assert abi.compare_rows(got, want, PI_TOL, P_TOL) == []
+    empty = synth.generate_native(cfg, 0, 0, P)
+    assert len(engine0.call_batch_host(empty, P)) == 0
+
+
+def test_bad_ids_are_reported_not_crashed(engine0):
+    cfg = synth.CONFIGS["C2"]
+    P = synth.params_for(cfg)
+    db = synth.generate_native(cfg, 0, 8, P)
+    db.umi[int(db.loci["read_off"][3]) + 5] = 1000       # out of the declared range
+    got = engine0.call_batch_host(db, P)
+    assert got["status"][3] & abi.ST_BAD_INPUT
+    assert (got["status"][[0, 1, 2, 4, 5, 6, 7]] == 0).all()
+    with pytest.raises(rows.RowError):
+        rows.format_rows(got, db, P, synth.CyclicRef())
+
+
+def test_full_size_properties(engine0):
+    """BASELINE.json's C2 at full size (10k loci) through size-independent properties: every locus
+    reports DP = depth, UMT = barcodes, sum of per-allele depths <= DP, PI_ref ~ barcodes * PI of a
+    clean barcode, and a checksum identical across two different launch shapes (whole batch vs two
+    halves)."""
+    cfg = synth.CONFIGS["C2"]
+    P = synth.params_for(cfg)
+    db = synth.generate_native(cfg, 0, cfg.n_loci, P)
+    got = engine0.call_batch_host(db, P)
+    assert (got["status"] == 0).all()
+    assert (got["cvg"] == cfg.depth).all() and (got["all_mt"] == cfg.n_umi).all()
+    assert (got["dp"].sum(axis=1) <= got["cvg"]).all()
+    assert (got["used_mt"] <= cfg.n_umi).all() and (got["used_mt"] >= cfg.n_umi - 2).all()
+    ref_ids = np.array([{"A": 0, "T": 1, "G": 2, "C": 3}[r] for r in db.ref])
+    pi_ref = got["pi"][np.arange(len(got)), ref_ids]
+    assert pi_ref.min() > 2.0 * cfg.n_umi and pi_ref.max() < 6.0 * cfg.n_umi
+    half = cfg.n_loci // 2
+    lo = synth.generate_native(cfg, 0, half, P)
+    hi = synth.generate_native(cfg, half, cfg.n_loci, P)
+    both = np.concatenate([engine0.call_batch_host(lo, P), engine0.call_batch_host(hi, P)])
+    assert both.tobytes() == got.tobytes()
