@@ -76,8 +76,10 @@ typedef struct smc_params {
 } smc_params;
 
 /* One per locus, 32 bytes. Reads of locus l occupy plane slots [read_off, read_off + n_reads);
- * read_off is a multiple of 4. umi ids are < n_umi; for each umi, frag ids are dense from 0 and
- * n_frag is the sum over umis of (max frag id + 1) (= allFrag, smCounter.py:483). */
+ * read_off is a multiple of 4. umi ids are < n_umi (dense, order of first appearance). frag ids are
+ * locus-level fragment slots < n_frag, grouped by barcode: the fragments of barcode u occupy one
+ * contiguous slot range, ranges ordered by u, each fragment's slot fixed by its first appearance
+ * within the barcode; n_frag = number of distinct fragments (= allFrag, smCounter.py:483). */
 typedef struct smc_locus {
     int64_t read_off;
     int32_t n_reads;

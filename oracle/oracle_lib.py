@@ -28,12 +28,26 @@ def lib():
     return _LIB
 
 
-def call_batch(db, cparams, row_dtype):
-    """db: smcounter_amd.features.DeviceBatch; cparams: ctypes smc_params; -> structured rows."""
+def call_batch(db, cparams, row_dtype, return_fragile=False):
+    """db: smcounter_amd.features.DeviceBatch; cparams: ctypes smc_params; -> structured rows
+    (and, on request, the per-locus count of barcodes whose consensus hinges on rounding)."""
     L = lib()
     assert L.smc_oracle_row_size() == row_dtype.itemsize
     rows = np.zeros(db.n_loci, row_dtype)
     loci = np.ascontiguousarray(db.loci)
+    if return_fragile:
+        fragile = np.zeros(db.n_loci, np.int32)
+        rc = L.smc_oracle_call_batch_ex(ctypes.byref(cparams), loci.ctypes.data_as(ctypes.c_void_p),
+                                        ctypes.c_int64(db.n_loci),
+                                        db.meta.ctypes.data_as(ctypes.c_void_p),
+                                        db.umi.ctypes.data_as(ctypes.c_void_p),
+                                        db.frag.ctypes.data_as(ctypes.c_void_p),
+                                        db.dist.ctypes.data_as(ctypes.c_void_p),
+                                        rows.ctypes.data_as(ctypes.c_void_p),
+                                        fragile.ctypes.data_as(ctypes.c_void_p))
+        if rc != 0:
+            raise RuntimeError("smc_oracle_call_batch_ex failed: %d" % rc)
+        return rows, fragile
     rc = L.smc_oracle_call_batch(ctypes.byref(cparams), loci.ctypes.data_as(ctypes.c_void_p),
                                  ctypes.c_int64(db.n_loci),
                                  db.meta.ctypes.data_as(ctypes.c_void_p),

@@ -138,8 +138,14 @@ static int tie_rank(int a, int n_keys) {
     return 64 + a;
 }
 
+/* `fragile`, when not NULL, receives the number of barcodes with >= 3 fragments whose two largest
+ * per-barcode prediction indices are equal to within 1e-9: whether such a barcode has a unique
+ * maximum (smCounter.py:514) is decided by floating-point rounding of products whose factor order is
+ * the iteration order of a dict (smCounter.py:62) - not pinned by the algorithm, so parity tests
+ * skip the MT-count columns of the few loci that contain one. */
 static int call_locus(const smc_params* P, const smc_locus* L, const uint32_t* meta, const uint32_t* umi,
-                      const uint32_t* frag, const uint32_t* dist, smc_row* R) {
+                      const uint32_t* frag, const uint32_t* dist, smc_row* R, int32_t* fragile) {
+    if (fragile) *fragile = 0;
     memset(R, 0, sizeof *R);
     R->max_allele = R->second_allele = -1;
     fill_cand(&R->cand[0], -1, 0, NULL, NULL, NULL);
@@ -159,14 +165,17 @@ static int call_locus(const smc_params* P, const smc_locus* L, const uint32_t* m
     int* in_bc = (int*)calloc((size_t)nU + 1, sizeof(int));
     int* bc_order = (int*)calloc((size_t)nU + 1, sizeof(int));
     int bad = 0;
-    /* allBcDict (smCounter.py:463-464): fragments per barcode over ALL reads */
+    /* allBcDict (smCounter.py:463-464): fragments per barcode over ALL reads.  frag[] is the
+     * locus-level slot; a barcode's fragments are the slots between its smallest and largest. */
+    for (int u = 0; u < nU; ++u) { foff[u] = L->n_frag; nfrag[u] = 0; }
     for (int i = 0; i < n; ++i) {
         uint32_t u = umi[i], f = frag[i];
-        if (u >= (uint32_t)nU || (meta[i] & 0xff) >= L->n_alleles) { bad = 1; continue; }
-        if ((int)f + 1 > nfrag[u]) nfrag[u] = (int)f + 1;
+        if (u >= (uint32_t)nU || f >= (uint32_t)L->n_frag || (meta[i] & 0xff) >= L->n_alleles) { bad = 1; continue; }
+        if ((int)f < foff[u]) foff[u] = (int)f;
+        if ((int)f + 1 > nfrag[u]) nfrag[u] = (int)f + 1;      /* end of the range, for now */
     }
     int64_t tot = 0;
-    for (int u = 0; u < nU; ++u) { foff[u] = (int)tot; tot += nfrag[u]; }
+    for (int u = 0; u < nU; ++u) { nfrag[u] = nfrag[u] > foff[u] ? nfrag[u] - foff[u] : 0; tot += nfrag[u]; }
     if (tot != L->n_frag) bad = 1;
     if (bad) {
         R->status = SMC_ST_BAD_INPUT;
@@ -200,7 +209,7 @@ static int call_locus(const smc_params* P, const smc_locus* L, const uint32_t* m
         if (inc) {                                                       /* :467-479 */
             uint32_t u = umi[i];
             if (!in_bc[u]) { in_bc[u] = 1; bc_order[n_bc++] = (int)u; }
-            frag_t* s = &ft[foff[u] + frag[i]];
+            frag_t* s = &ft[frag[i]];
             double prob = pow(10.0, -bq / 10.0);
             if (!s->present) {
                 s->present = 1; s->paired = 0; s->base = (unsigned char)a; s->prob = prob; s->seq = stamp++;
@@ -297,6 +306,11 @@ static int call_locus(const smc_params* P, const smc_locus* L, const uint32_t* m
             if (pred[k] > mx) mx = pred[k];
         }
         for (int k = 0; k < nk; ++k) if (pred[k] == mx) { n_max++; arg = k; }
+        if (fragile && nf >= 3) {
+            int close = 0;
+            for (int k = 0; k < nk; ++k) if (fabs(pred[k] - mx) <= 1e-9 * (fabs(mx) > 1 ? fabs(mx) : 1)) close++;
+            if (close >= 2) (*fragile)++;
+        }
         if (n_max == 1) {                                                /* :515-519 */
             mtcnt[keys[arg]]++;
             if (pred[arg] > P->smt) strong[keys[arg]]++;
@@ -352,7 +366,19 @@ int smc_oracle_call_batch(const smc_params* P, const smc_locus* loci, int64_t n_
     for (int64_t l = 0; l < n_loci; ++l) {
         const smc_locus* L = &loci[l];
         if (L->n_alleles > SMC_MAX_ALLELES) return -1;
-        call_locus(P, L, meta + L->read_off, umi + L->read_off, frag + L->read_off, dist + L->read_off, &rows[l]);
+        call_locus(P, L, meta + L->read_off, umi + L->read_off, frag + L->read_off, dist + L->read_off, &rows[l], NULL);
+    }
+    return 0;
+}
+
+int smc_oracle_call_batch_ex(const smc_params* P, const smc_locus* loci, int64_t n_loci, const uint32_t* meta,
+                             const uint32_t* umi, const uint32_t* frag, const uint32_t* dist, smc_row* rows,
+                             int32_t* fragile) {
+    for (int64_t l = 0; l < n_loci; ++l) {
+        const smc_locus* L = &loci[l];
+        if (L->n_alleles > SMC_MAX_ALLELES) return -1;
+        call_locus(P, L, meta + L->read_off, umi + L->read_off, frag + L->read_off, dist + L->read_off, &rows[l],
+                   fragile ? &fragile[l] : NULL);
     }
     return 0;
 }

@@ -30,6 +30,12 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise SmcError("HIP library missing: %s - run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(or python -m smcounter_amd.build); there is no CPU fallback" % LIB_PATH)
+    # PyTorch-ROCm ships its own HIP runtime; it must be the first one mapped into the process, or
+    # torch later finds "No HIP GPUs" behind the system libamdhip64 this library would pull in.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
     L.smc_abi_version.restype = ctypes.c_int

@@ -169,6 +169,11 @@ int smc_synth_generate(const smc_synth_cfg* c, int64_t lo, int64_t hi, uint32_t*
                 if (r.allele == 253 && first_dst > R) first_dst = i;
                 out[i] = r;
             }
+            // fragment slots are locus-level, grouped by (new) barcode id
+            std::vector<int> ubase(U + 1, 0);
+            for (int u = 0; u < U; ++u) ubase[ufirst[u] + 1] = fcount[u];
+            for (int u = 0; u < U; ++u) ubase[u + 1] += ubase[u];
+            for (int i = 0; i < R; ++i) out[i].frag += (uint32_t)ubase[out[i].umi];
             const int ins_id = first_ins < first_dst ? 6 : 7;
             const int dst_id = first_dst < first_ins ? 6 : (first_ins <= R ? 7 : 6);
             const int64_t off = (l - lo) * stride;

@@ -65,11 +65,29 @@ enum {
     M_NEEDFIX,
 };
 
+#ifdef SMC_STAMPS
+// diagnostic build only (scripts/stamps.py): per-phase cycle totals of k_call_loci, thread 0 of each block
+__device__ unsigned long long g_stamps[16];
+#define STAMP(k)                                                             \
+    do {                                                                     \
+        if (threadIdx.x == 0) {                                              \
+            const unsigned long long t_ = clock64();                         \
+            atomicAdd(&g_stamps[k], t_ - t_prev_);                           \
+            t_prev_ = t_;                                                    \
+        }                                                                    \
+    } while (0)
+#define STAMP_INIT() unsigned long long t_prev_ = clock64()
+#else
+#define STAMP(k) do { } while (0)
+#define STAMP_INIT() do { } while (0)
+#endif
+
 #define NT_K1 11  // tallies kept per allele in LDS: the SMC_T_* of the header, without the pad
 
 __device__ __forceinline__ uint32_t lds_hdr_bytes(int a_cap) {
     // Hdr + tal[a_cap][SMC_NT] + pifx[a_cap] (u64) + mtc[a_cap] + strong[a_cap] + row stage
-    return (uint32_t)(sizeof(Hdr) + a_cap * SMC_NT * 4 + a_cap * 8 + a_cap * 4 + a_cap * 4 + sizeof(smc_row));
+    // + lut[LUT_N] doubles
+    return (uint32_t)(sizeof(Hdr) + a_cap * SMC_NT * 4 + a_cap * 8 + a_cap * 4 + a_cap * 4 + sizeof(smc_row) + 128 * 8);
 }
 
 __device__ __forceinline__ double wave_reduce_mul(double v, int width) {
@@ -151,9 +169,13 @@ __device__ __forceinline__ ReadRec decode_read(uint32_t m, uint32_t d, const KPa
     return r;
 }
 
-// pow(10, x) and log10 in double; the LUT of 10^(-q/10) is computed on the host with the same libm
-// the CPU restatement uses.
-__device__ __forceinline__ double pcr_of(int cnt, double denom) { return pow(10.0, -6.0 * ((cnt + 0.5) / denom)); }
+// 10^x and log10 in double.  The LUT of 10^(-q/10) is computed on the host with the same libm the CPU
+// restatement uses; the PCR-error terms and the final -log10 use the device library (a few ulp from
+// glibc's pow/log10: invisible at the 1e-6 tolerance on PI, and symmetric across alleles so exact
+// ties between alleles stay exact).
+__device__ __forceinline__ double pcr_of(int cnt, double denom) { return exp10(-6.0 * ((cnt + 0.5) / denom)); }
+
+#define LUT_N 128   // qualities with an LDS-resident error probability; rarer ones read the global table
 
 // ------------------------------------------------------------------------------------------
 // kernel 1: scan + group + score + rank
@@ -162,17 +184,17 @@ template <int BLOCK, bool GLOBAL_TABLES>
 __global__ __launch_bounds__(BLOCK) void k_call_loci(
     KParams P, const smc_locus* __restrict__ loci, const int* __restrict__ order, int a_cap,
     const uint32_t* __restrict__ g_meta, const uint32_t* __restrict__ g_umi, const uint32_t* __restrict__ g_frag,
-    const uint32_t* __restrict__ g_dist, const double* __restrict__ lut, smc_row* __restrict__ rows,
+    const uint32_t* __restrict__ g_dist, const double* __restrict__ g_lut, smc_row* __restrict__ rows,
     uint8_t* __restrict__ scratch, const int64_t* __restrict__ scratch_off) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = order[blockIdx.x];
     const smc_locus L = loci[li];
     const int n = L.n_reads, nU = L.n_umi, nF = L.n_frag, nA = L.n_alleles;
-    const uint32_t* meta = g_meta + L.read_off;
-    const uint32_t* umi = g_umi + L.read_off;
-    const uint32_t* frag = g_frag + L.read_off;
-    const uint32_t* dist = g_dist + L.read_off;
+    const uint4* meta4 = (const uint4*)(g_meta + L.read_off);
+    const uint4* umi4 = (const uint4*)(g_umi + L.read_off);
+    const uint4* frag4 = (const uint4*)(g_frag + L.read_off);
+    const uint4* dist4 = (const uint4*)(g_dist + L.read_off);
 
     // ---- carve LDS
     Hdr* H = (Hdr*)smem;
@@ -181,25 +203,30 @@ __global__ __launch_bounds__(BLOCK) void k_call_loci(
     uint32_t* mtc = (uint32_t*)(pifx + a_cap);
     uint32_t* strong = mtc + a_cap;
     smc_row* rowst = (smc_row*)(strong + a_cap);
+    double* lut = (double*)(rowst + 1);                              // [LUT_N]
     unsigned char* tab = GLOBAL_TABLES ? (scratch + scratch_off[blockIdx.x]) : (smem + lds_hdr_bytes(a_cap));
-    uint32_t* umi_base = (uint32_t*)tab;                              // [nU+1]
+    uint32_t* umi_base = (uint32_t*)tab;                              // [nU+1] first slot of each barcode
     uint32_t* fmin = umi_base + (nU + 1);                             // [nF]
     uint32_t* fmax = fmin + nF;                                       // [nF]
     unsigned char* umi_flag = (unsigned char*)(fmax + nF);            // [nU]
 
+    STAMP_INIT();
     // ---- S0: init
     {
         uint32_t* z = (uint32_t*)smem;
-        const int nz = (int)(lds_hdr_bytes(a_cap) / 4);
+        const int nz = (int)((sizeof(Hdr) + a_cap * 64 + sizeof(smc_row)) / 4);
         for (int i = tid; i < nz; i += BLOCK) z[i] = 0;
-        for (int i = tid; i <= nU; i += BLOCK) umi_base[i] = 0;
-        for (int i = tid; i < nU; i += BLOCK) umi_flag[i] = 0;
+        for (int i = tid; i < LUT_N; i += BLOCK) lut[i] = g_lut[i];
+        for (int i = tid; i < nU; i += BLOCK) { umi_base[i] = 0xFFFFFFFFu; umi_flag[i] = 0; }
         for (int i = tid; i < nF; i += BLOCK) { fmin[i] = 0xFFFFFFFFu; fmax[i] = 0u; }
+        if (tid == 0) umi_base[nU] = (uint32_t)nF;
     }
     __syncthreads();
+    STAMP(0);
 
-    // ---- P1: per-read inclusion test and tallies (smCounter.py:368-460), fragments per barcode
-    // (allBcDict, :463-464), which barcodes enter bcDict (:467-468).
+    // ---- P1: ONE pass over the reads, 4 reads per lane per step (16-byte loads of each plane):
+    // inclusion test and tallies (smCounter.py:368-460), first slot of each barcode, which barcodes
+    // enter bcDict (:467-468), and per fragment the smallest / largest key of its included reads.
     {
         uint32_t acc[4][9];   // wave-uniform (SGPR) tallies of A,T,G,C
 #pragma unroll
@@ -207,56 +234,77 @@ __global__ __launch_bounds__(BLOCK) void k_call_loci(
 #pragma unroll
             for (int k = 0; k < 9; ++k) acc[a][k] = 0;
         uint32_t n_inc_w = 0, err_w = 0;
-        for (int base = 0; base < n; base += BLOCK) {
-            const int i = base + tid;
-            const bool valid = i < n;
-            uint32_t m = 0, u = 0, f = 0, d = 0;
-            if (valid) { m = meta[i]; u = umi[i]; f = frag[i]; d = dist[i]; }
-            ReadRec r = decode_read(m, d, P);
-            bool ok = valid && u < (uint32_t)nU && r.allele < nA;
-            if (__ballot(valid && !ok)) err_w = 1;
-            const bool inc = ok && r.inc;
-            const bool regular = r.kind == SMC_KIND_BASE;
-            const bool r1i = inc && regular && !r.r2, r2i = inc && regular && r.r2;
-            const unsigned long long b_fwd = __ballot(ok && r.kind != SMC_KIND_GAP && !r.rev);
-            const unsigned long long b_rev = __ballot(ok && r.kind != SMC_KIND_GAP && r.rev);
-            const unsigned long long b_lowq = __ballot(ok && r.lowq);
-            const unsigned long long b_r1n = __ballot(r1i);
-            const unsigned long long b_r1le = __ballot(r1i && r.dbc <= 20);
-            const unsigned long long b_r2n = __ballot(r2i);
-            const unsigned long long b_r2bc = __ballot(r2i && r.dbc <= 20);
-            const unsigned long long b_r2pr = __ballot(r2i && r.dpr <= P.primer_dist);
-            n_inc_w += __popcll(__ballot(inc));
+        const int n4 = (n + 3) >> 2;
+        uint4 m4, u4, f4, d4;
+        {
+            const int q = tid;
+            if (q < n4) { m4 = meta4[q]; u4 = umi4[q]; f4 = frag4[q]; d4 = dist4[q]; }
+        }
+        for (int qb = 0; qb < n4; qb += BLOCK) {
+            const int q = qb + tid;
+            const uint4 cm = m4, cu = u4, cf = f4, cd = d4;
+            {   // prefetch the next step while this one is processed
+                const int qn = q + BLOCK;
+                if (qn < n4) { m4 = meta4[qn]; u4 = umi4[qn]; f4 = frag4[qn]; d4 = dist4[qn]; }
+            }
+            const uint32_t ms[4] = {cm.x, cm.y, cm.z, cm.w}, us[4] = {cu.x, cu.y, cu.z, cu.w};
+            const uint32_t fs[4] = {cf.x, cf.y, cf.z, cf.w}, ds[4] = {cd.x, cd.y, cd.z, cd.w};
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const unsigned long long ma = __ballot(ok && r.allele == a);
-                if (ma) {
-                    acc[a][SMC_T_CNT] += __popcll(ma);
-                    acc[a][SMC_T_FWD] += __popcll(ma & b_fwd);
-                    acc[a][SMC_T_REV] += __popcll(ma & b_rev);
-                    acc[a][SMC_T_LOWQ] += __popcll(ma & b_lowq);
-                    acc[a][SMC_T_R1N] += __popcll(ma & b_r1n);
-                    acc[a][SMC_T_R1LE] += __popcll(ma & b_r1le);
-                    acc[a][SMC_T_R2N] += __popcll(ma & b_r2n);
-                    acc[a][SMC_T_R2BCLE] += __popcll(ma & b_r2bc);
-                    acc[a][SMC_T_R2PRLE] += __popcll(ma & b_r2pr);
+            for (int k = 0; k < 4; ++k) {
+                const int i = 4 * q + k;
+                const bool valid = q < n4 && i < n;
+                const uint32_t u = us[k], f = fs[k];
+                ReadRec r = decode_read(ms[k], ds[k], P);
+                const bool ok = valid && u < (uint32_t)nU && f < (uint32_t)nF && r.allele < nA;
+                if (__ballot(valid && !ok)) err_w = 1;
+                const bool inc = ok && r.inc;
+                const bool regular = r.kind == SMC_KIND_BASE;
+                const bool r1i = inc && regular && !r.r2, r2i = inc && regular && r.r2;
+                const unsigned long long b_fwd = __ballot(ok && r.kind != SMC_KIND_GAP && !r.rev);
+                const unsigned long long b_rev = __ballot(ok && r.kind != SMC_KIND_GAP && r.rev);
+                const unsigned long long b_lowq = __ballot(ok && r.lowq);
+                const unsigned long long b_r1n = __ballot(r1i);
+                const unsigned long long b_r1le = __ballot(r1i && r.dbc <= 20);
+                const unsigned long long b_r2n = __ballot(r2i);
+                const unsigned long long b_r2bc = __ballot(r2i && r.dbc <= 20);
+                const unsigned long long b_r2pr = __ballot(r2i && r.dpr <= P.primer_dist);
+                n_inc_w += __popcll(__ballot(inc));
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const unsigned long long ma = __ballot(ok && r.allele == a);
+                    if (ma) {
+                        acc[a][SMC_T_CNT] += __popcll(ma);
+                        acc[a][SMC_T_FWD] += __popcll(ma & b_fwd);
+                        acc[a][SMC_T_REV] += __popcll(ma & b_rev);
+                        acc[a][SMC_T_LOWQ] += __popcll(ma & b_lowq);
+                        acc[a][SMC_T_R1N] += __popcll(ma & b_r1n);
+                        acc[a][SMC_T_R1LE] += __popcll(ma & b_r1le);
+                        acc[a][SMC_T_R2N] += __popcll(ma & b_r2n);
+                        acc[a][SMC_T_R2BCLE] += __popcll(ma & b_r2bc);
+                        acc[a][SMC_T_R2PRLE] += __popcll(ma & b_r2pr);
+                    }
                 }
-            }
-            if (ok && r.allele >= 4) {   // rare alleles: straight LDS atomics
-                uint32_t* t = tal + r.allele * SMC_NT;
-                atomicAdd(&t[SMC_T_CNT], 1u);
-                if (r.kind != SMC_KIND_GAP) atomicAdd(&t[r.rev ? SMC_T_REV : SMC_T_FWD], 1u);
-                if (r.lowq) atomicAdd(&t[SMC_T_LOWQ], 1u);
-                if (r1i) { atomicAdd(&t[SMC_T_R1N], 1u); if (r.dbc <= 20) atomicAdd(&t[SMC_T_R1LE], 1u); }
-                if (r2i) {
-                    atomicAdd(&t[SMC_T_R2N], 1u);
-                    if (r.dbc <= 20) atomicAdd(&t[SMC_T_R2BCLE], 1u);
-                    if (r.dpr <= P.primer_dist) atomicAdd(&t[SMC_T_R2PRLE], 1u);
+                if (ok && r.allele >= 4) {   // rare alleles: straight LDS atomics
+                    uint32_t* t = tal + r.allele * SMC_NT;
+                    atomicAdd(&t[SMC_T_CNT], 1u);
+                    if (r.kind != SMC_KIND_GAP) atomicAdd(&t[r.rev ? SMC_T_REV : SMC_T_FWD], 1u);
+                    if (r.lowq) atomicAdd(&t[SMC_T_LOWQ], 1u);
+                    if (r1i) { atomicAdd(&t[SMC_T_R1N], 1u); if (r.dbc <= 20) atomicAdd(&t[SMC_T_R1LE], 1u); }
+                    if (r2i) {
+                        atomicAdd(&t[SMC_T_R2N], 1u);
+                        if (r.dbc <= 20) atomicAdd(&t[SMC_T_R2BCLE], 1u);
+                        if (r.dpr <= P.primer_dist) atomicAdd(&t[SMC_T_R2PRLE], 1u);
+                    }
                 }
-            }
-            if (ok) {
-                atomicMax(&umi_base[u], f + 1u);
-                if (inc) umi_flag[u] = 1;
+                if (ok) {
+                    atomicMin(&umi_base[u], f);
+                    if (inc) {
+                        umi_flag[u] = 1;
+                        const uint32_t key = make_key(i, r.allele, r.bq_eff);
+                        atomicMin(&fmin[f], key);
+                        atomicMax(&fmax[f], key);
+                    }
+                }
             }
         }
         if (lane == 0) {
@@ -270,21 +318,24 @@ __global__ __launch_bounds__(BLOCK) void k_call_loci(
         }
     }
     __syncthreads();
+    STAMP(1);
 
-    // ---- S2: barcode bookkeeping: allMT, bcDict size, fragment offsets
+    // ---- S2: barcode bookkeeping: allMT (:482), size of bcDict, slot ranges must be ordered
     {
-        uint32_t nbc = 0, allmt = 0;
-        for (int u = tid; u < nU; u += BLOCK) { nbc += umi_flag[u]; allmt += umi_base[u] > 0; }
+        uint32_t nbc = 0, allmt = 0, bad = 0;
+        for (int u = tid; u < nU; u += BLOCK) {
+            const uint32_t b0 = umi_base[u], b1 = umi_base[u + 1];
+            nbc += umi_flag[u];
+            allmt += b0 != 0xFFFFFFFFu;
+            bad |= (b0 == 0xFFFFFFFFu) || b1 <= b0 || (u == 0 && b0 != 0);
+        }
         nbc = wave_reduce_add((int)nbc, WAVE);
         allmt = wave_reduce_add((int)allmt, WAVE);
+        if (__ballot(bad != 0) && lane == 0) H->misc[M_ERR] = 1;
         if (lane == 0) { atomicAdd(&H->misc[M_NBC], nbc); atomicAdd(&H->misc[M_ALLMT], allmt); }
     }
     __syncthreads();
-    {
-        uint32_t tot = block_exclusive_scan<BLOCK>(umi_base, nU, H->scan_tmp);
-        if (tid == 0) { umi_base[nU] = tot; H->misc[M_TOTFRAG] = tot; if (tot != (uint32_t)nF) H->misc[M_ERR] = 1; }
-    }
-    __syncthreads();
+    STAMP(2);
     const uint32_t n_bc = H->misc[M_NBC];
     const int used = (int)n_bc < P.ds ? (int)n_bc : P.ds;             // smCounter.py:489
     smc_row* out = rows + li;
@@ -295,7 +346,7 @@ __global__ __launch_bounds__(BLOCK) void k_call_loci(
             R->status = H->misc[M_ERR] ? SMC_ST_BAD_INPUT : SMC_ST_ZERO_COVERAGE;
             R->cvg = n;
             R->all_mt = H->misc[M_ALLMT];
-            R->all_frag = H->misc[M_TOTFRAG];
+            R->all_frag = nF;
             R->max_allele = R->second_allele = -1;
             for (int k = 0; k < 4; ++k) R->dp[k] = tal[k * SMC_NT + SMC_T_CNT];
             for (int c = 0; c < 2; ++c) {
@@ -310,91 +361,95 @@ __global__ __launch_bounds__(BLOCK) void k_call_loci(
         return;
     }
 
-    // ---- P2: fragment table. Included reads only (smCounter.py:467)
-    for (int base = 0; base < n; base += BLOCK) {
-        const int i = base + tid;
-        if (i < n) {
-            const uint32_t m = meta[i];
-            ReadRec r = decode_read(m, 0, P);
-            if (r.inc) {
-                const uint32_t s = umi_base[umi[i]] + frag[i];
-                const uint32_t key = make_key(i, r.allele, r.bq_eff);
-                atomicMin(&fmin[s], key);
-                atomicMax(&fmax[s], key);
+    // ---- R: mate merge (smCounter.py:468-479), assuming every fragment has <= 2 included reads;
+    // the count of reads so explained is checked against the number of included reads below.
+    auto resolve = [&](bool honour_marks) {
+        uint32_t c = 0;
+        for (int sb = 0; sb < nF; sb += BLOCK) {
+            const int s = sb + tid;
+            bool conc = false, disc = false;
+            int ev_allele = 0;
+            if (s < nF) {
+                const uint32_t a = fmin[s], b = fmax[s];
+                uint32_t st = 0;
+                const bool marked = honour_marks && b == 0xFFFFFFFFu;
+                if (!marked && a != 0xFFFFFFFFu) {
+                    const int a1 = KEY_ALLELE(a), q1 = KEY_BQ(a);
+                    if (a == b) {
+                        st = make_state(a1, q1, false);
+                        c += 1;
+                    } else {
+                        c += 2;
+                        const int a2 = KEY_ALLELE(b), q2 = KEY_BQ(b);
+                        if (a2 == a1 || a2 == N_ID) {
+                            // prob = max(prob_new, prob_old)  <=>  min quality  (:473)
+                            st = make_state(a1, q1 < q2 ? q1 : q2, true);
+                            if (a2 == a1) { conc = true; ev_allele = a1; }
+                        } else {
+                            disc = true; ev_allele = a2;                 // del bcDict[BC][readid] (:478)
+                        }
+                    }
+                }
+                if (!marked) fmin[s] = st;
+            }
+            // concordant / discordant pair tallies: wave-aggregated for A,T,G,C
+            const unsigned long long bc = __ballot(conc), bd = __ballot(disc);
+            if (bc | bd) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const unsigned long long ma = __ballot((conc || disc) && ev_allele == a);
+                    if (ma && lane == 0) {
+                        const int nc = __popcll(ma & bc), nd = __popcll(ma & bd);
+                        if (nc) atomicAdd(&tal[a * SMC_NT + SMC_T_CONCORD], (uint32_t)nc);
+                        if (nd) atomicAdd(&tal[a * SMC_NT + SMC_T_DISCORD], (uint32_t)nd);
+                    }
+                }
+                if ((conc || disc) && ev_allele >= 4)
+                    atomicAdd(&tal[ev_allele * SMC_NT + (conc ? SMC_T_CONCORD : SMC_T_DISCORD)], 1u);
             }
         }
-    }
-    __syncthreads();
-
-    // ---- R1: do all fragments have <= 2 included reads?
+        return c;
+    };
     {
-        uint32_t c = 0;
-        for (int s = tid; s < nF; s += BLOCK) {
-            const uint32_t a = fmin[s], b = fmax[s];
-            c += (a == 0xFFFFFFFFu) ? 0u : (a == b ? 1u : 2u);
-        }
+        uint32_t c = resolve(false);
         c = wave_reduce_add((int)c, WAVE);
         if (lane == 0 && c) atomicAdd(&H->misc[M_RESOLVED], c);
     }
     __syncthreads();
-    const bool need_fix = H->misc[M_RESOLVED] != H->misc[M_NINC];
-    if (need_fix) {
-        // some read name has >= 3 included alignments on this locus: mark those fragments
-        for (int base = 0; base < n; base += BLOCK) {
-            const int i = base + tid;
-            if (i < n) {
-                ReadRec r = decode_read(meta[i], 0, P);
-                if (r.inc) {
-                    const uint32_t s = umi_base[umi[i]] + frag[i];
-                    const uint32_t key = make_key(i, r.allele, r.bq_eff);
-                    const uint32_t lo = fmin[s], hi = fmax[s];
-                    if (key != lo && key != hi) fmax[s] = 0xFFFFFFFFu;   // idempotent marker
-                }
+    STAMP(4);
+    if (H->misc[M_RESOLVED] != H->misc[M_NINC]) {
+        // Some read name has >= 3 included alignments on this locus (rare): redo the fragment table,
+        // mark those fragments, resolve the others as above and replay the marked ones in read order.
+        const uint32_t* meta = g_meta + L.read_off;
+        const uint32_t* umi = g_umi + L.read_off;
+        const uint32_t* frag = g_frag + L.read_off;
+        for (int i = tid; i < nF; i += BLOCK) { fmin[i] = 0xFFFFFFFFu; fmax[i] = 0u; }
+        for (int a = tid; a < a_cap; a += BLOCK) tal[a * SMC_NT + SMC_T_CONCORD] = tal[a * SMC_NT + SMC_T_DISCORD] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += BLOCK) {
+            ReadRec r = decode_read(meta[i], 0, P);
+            if (r.inc) {
+                const uint32_t key = make_key(i, r.allele, r.bq_eff);
+                atomicMin(&fmin[frag[i]], key);
+                atomicMax(&fmax[frag[i]], key);
             }
         }
         __syncthreads();
-    }
-
-    // ---- R2: mate merge for fragments with <= 2 included reads (smCounter.py:468-479)
-    for (int sb = 0; sb < nF; sb += BLOCK) {
-        const int s = sb + tid;
-        bool conc = false, disc = false;
-        int ev_allele = 0;
-        if (s < nF) {
-            const uint32_t a = fmin[s], b = fmax[s];
-            uint32_t st = 0;
-            if (b == 0xFFFFFFFFu) {
-                st = 0;   // replayed below
-            } else if (a != 0xFFFFFFFFu) {
-                const int a1 = KEY_ALLELE(a), q1 = KEY_BQ(a);
-                if (a == b) {
-                    st = make_state(a1, q1, false);
-                } else {
-                    const int a2 = KEY_ALLELE(b), q2 = KEY_BQ(b);
-                    if (a2 == a1 || a2 == N_ID) {
-                        // prob = max(prob_new, prob_old)  <=>  min quality  (:473)
-                        st = make_state(a1, q1 < q2 ? q1 : q2, true);
-                        if (a2 == a1) { conc = true; ev_allele = a1; }
-                    } else {
-                        st = 0;                                          // del bcDict[BC][readid] (:478)
-                        disc = true; ev_allele = a2;
-                    }
-                }
+        for (int i = tid; i < n; i += BLOCK) {
+            ReadRec r = decode_read(meta[i], 0, P);
+            if (r.inc) {
+                const uint32_t s = frag[i], key = make_key(i, r.allele, r.bq_eff);
+                const uint32_t lo = fmin[s], hi = fmax[s];
+                if (key != lo && key != hi) fmax[s] = 0xFFFFFFFFu;       // idempotent marker
             }
-            if (b != 0xFFFFFFFFu) fmin[s] = st;
         }
-        if (__ballot(conc || disc)) {
-            if (conc) atomicAdd(&tal[ev_allele * SMC_NT + SMC_T_CONCORD], 1u);
-            if (disc) atomicAdd(&tal[ev_allele * SMC_NT + SMC_T_DISCORD], 1u);
-        }
-    }
-    __syncthreads();
-    if (need_fix) {
-        // sequential replay, one wave per marked fragment
+        __syncthreads();
+        (void)resolve(true);
+        __syncthreads();
         constexpr int NW = BLOCK / WAVE;
-        for (int sb = 0; sb < nF; sb += 1) {
+        for (int sb = 0; sb < nF; ++sb) {
             if (fmax[sb] != 0xFFFFFFFFu) continue;            // uniform over the block (LDS value)
-            if ((sb % NW) != wid) continue;                   // uniform over the wave
+            if ((sb % NW) != wid) continue;                   // one wave per marked fragment
             bool present = false, paired = false;
             int sa = 0, sq = 0;
             for (int base = 0; base < n; base += WAVE) {
@@ -404,7 +459,7 @@ __global__ __launch_bounds__(BLOCK) void k_call_loci(
                 r.allele = 0; r.bq_eff = 0;
                 if (i < n) {
                     r = decode_read(meta[i], 0, P);
-                    hit = r.inc && (umi_base[umi[i]] + frag[i]) == (uint32_t)sb;
+                    hit = r.inc && frag[i] == (uint32_t)sb;
                 }
                 unsigned long long hm = __ballot(hit);
                 while (hm) {
@@ -426,11 +481,10 @@ __global__ __launch_bounds__(BLOCK) void k_call_loci(
         __syncthreads();
     }
 
+    STAMP(5);
     // ---- down-sampling stand-in (non-parity; the reference random.samples, :496-498):
     // keep the `ds` lowest barcode ids among bcDict's keys.
     if ((int)n_bc > P.ds) {
-        // rank of each flagged barcode = exclusive prefix count of flags; reuse fmax[] as scratch
-        // is not possible (nU may exceed nF), so count serially per thread block-stride: rare path.
         if (tid == 0) {
             int k = 0;
             for (int u = 0; u < nU; ++u)
@@ -454,28 +508,40 @@ __global__ __launch_bounds__(BLOCK) void k_call_loci(
         int c3 = 0, c5 = 0, c7 = 0, c10 = 0, ufrag = 0;
         uint32_t touch_lo = 0, touch_hi = 0;
         const double pne = 1.0 - 3e-5;                                 // pcr_no_error, :20
+        const int refa = L.ref_allele;
+        auto prob_of = [&](uint32_t st) -> double {                    // :65-68
+            if (!(st & ST_PAIRED)) return 0.1;
+            const int q = KEY_BQ(st);
+            return q < LUT_N ? lut[q] : g_lut[q];
+        };
 
         for (int u = grp; u < nU; u += ngrp) {
             if (!umi_flag[u]) continue;                                // not a key of bcDict
             const int b0 = umi_base[u], b1 = umi_base[u + 1];
-            // pass A: fragment count, allele set, P(no sequencing error)
-            int nf = 0;
+            // pass A: fragment count, allele set, P(no sequencing error); speculatively also the
+            // count and product for the locus's reference allele (the only allele of most barcodes)
+            int nf = 0, cnt_ref = 0;
             uint32_t mlo = 0, mhi = 0;
-            double rightP = 1.0;
+            double rightP = 1.0, prod_ref = 1.0;
             for (int s = b0 + j; s < b1; s += G) {
                 const uint32_t st = fmin[s];
                 if (st & ST_PRESENT) {
                     ++nf;
                     const int a = KEY_ALLELE(st);
                     if (a < 32) mlo |= 1u << a; else mhi |= 1u << (a - 32);
-                    const double p = (st & ST_PAIRED) ? lut[KEY_BQ(st)] : 0.1;   // :65-68
-                    rightP *= 1.0 - p;
+                    const double p = prob_of(st), q1 = 1.0 - p;
+                    rightP *= q1;
+                    const bool same = a == refa;
+                    cnt_ref += same;
+                    prod_ref *= same ? q1 : p;
                 }
             }
             nf = wave_reduce_add(nf, G);
+            cnt_ref = wave_reduce_add(cnt_ref, G);
             mlo = wave_reduce_or(mlo, G);
             mhi = wave_reduce_or(mhi, G);
             rightP = wave_reduce_mul(rightP, G);
+            prod_ref = wave_reduce_mul(prod_ref, G);
             const unsigned long long mask = ((unsigned long long)mhi << 32) | mlo;
             if (j == 0) { ufrag += nf; c3 += nf >= 3; c5 += nf >= 5; c7 += nf >= 7; c10 += nf >= 10; }
 
@@ -506,25 +572,29 @@ __global__ __launch_bounds__(BLOCK) void k_call_loci(
                     for (int k = 0; k < 4; ++k)
                         if (k < n_exist) { ida[k] = __ffsll((long long)mm) - 1; mm &= mm - 1; }
                 }
-                // pass B: per existing allele, count and P(reads | allele)  (:62-77)
-                for (int s = b0 + j; s < b1; s += G) {
-                    const uint32_t st = fmin[s];
-                    if (st & ST_PRESENT) {
-                        const int a = KEY_ALLELE(st);
-                        const double p = (st & ST_PAIRED) ? lut[KEY_BQ(st)] : 0.1;
+                if (refa < 64 && mask == (1ull << refa)) {
+                    cnta[0] = cnt_ref; proda[0] = prod_ref;            // speculation hit: no second pass
+                } else {
+                    // pass B: per existing allele, count and P(reads | allele)  (:62-77)
+                    for (int s = b0 + j; s < b1; s += G) {
+                        const uint32_t st = fmin[s];
+                        if (st & ST_PRESENT) {
+                            const int a = KEY_ALLELE(st);
+                            const double p = prob_of(st);
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (k < n_exist) {
-                                const bool same = a == ida[k];
-                                cnta[k] += same;
-                                proda[k] *= same ? 1.0 - p : p;
-                            }
+                            for (int k = 0; k < 4; ++k)
+                                if (k < n_exist) {
+                                    const bool same = a == ida[k];
+                                    cnta[k] += same;
+                                    proda[k] *= same ? 1.0 - p : p;
+                                }
+                        }
                     }
-                }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    cnta[k] = wave_reduce_add(cnta[k], G);
-                    proda[k] = wave_reduce_mul(proda[k], G);
+                    for (int k = 0; k < 4; ++k) {
+                        cnta[k] = wave_reduce_add(cnta[k], G);
+                        proda[k] = wave_reduce_mul(proda[k], G);
+                    }
                 }
                 // PCR-error terms (:79-81); min over the other keys == value at their max count
                 int max1 = -1, max2 = -1, arg1 = -1;
@@ -542,9 +612,8 @@ __global__ __launch_bounds__(BLOCK) void k_call_loci(
                 for (int k = 0; k < 4; ++k)
                     if (k < n_exist) {
                         int other = (k == arg1) ? max2 : max1;
-                        if (npad > 0 && other < 0) other = 0;
-                        if (npad > 0 && other < 0) other = 0;
-                        tmpv[k] = pne * proda[k] + rightP * pcr_of(other < 0 ? 0 : other, denom);   // :86
+                        if (other < 0) other = 0;                      // only padded keys besides this one
+                        tmpv[k] = pne * proda[k] + rightP * pcr_of(other, denom);   // :86
                         sumP += tmpv[k];
                     }
                 const double padOut = rightP * prodpcr;                // :88-91
@@ -604,7 +673,7 @@ __global__ __launch_bounds__(BLOCK) void k_call_loci(
                     for (int s = b0 + j; s < b1; s += G) {
                         const uint32_t st = fmin[s];
                         if (st & ST_PRESENT) {
-                            const double p = (st & ST_PAIRED) ? lut[KEY_BQ(st)] : 0.1;
+                            const double p = prob_of(st);
                             const bool same = (int)KEY_ALLELE(st) == a;
                             cnt += same;
                             prod *= same ? 1.0 - p : p;
@@ -614,14 +683,12 @@ __global__ __launch_bounds__(BLOCK) void k_call_loci(
                     prod = wave_reduce_mul(prod, G);
                 };
                 int max1 = -1, max2 = -1, arg1 = -1;
-                double prodpcr = 1.0;
                 for (unsigned long long mm = mask; mm; mm &= mm - 1) {
                     const int a = __ffsll((long long)mm) - 1;
                     int c; double pr;
                     scan_allele(a, c, pr);
                     if (c > max1) { max2 = max1; max1 = c; arg1 = a; }
                     else if (c > max2) max2 = c;
-                    prodpcr *= pcr_of(c, denom);
                 }
                 double sumP = 0.0;
                 for (unsigned long long mm = mask; mm; mm &= mm - 1) {
@@ -681,6 +748,7 @@ __global__ __launch_bounds__(BLOCK) void k_call_loci(
             atomicOr(&H->misc[M_TOUCH_LO], touch_lo); atomicOr(&H->misc[M_TOUCH_HI], touch_hi);
         }
         __syncthreads();
+        STAMP(6);
 
         // ---- E: ranking and candidates (:534-555), one thread
         if (tid == 0) {
@@ -707,7 +775,7 @@ __global__ __launch_bounds__(BLOCK) void k_call_loci(
             R->status = ((int)n_bc > P.ds) ? SMC_ST_DOWNSAMPLED : SMC_ST_OK;
             R->n_touched = nkeys;
             R->cvg = n;
-            R->all_frag = H->misc[M_TOTFRAG];
+            R->all_frag = nF;
             R->all_mt = H->misc[M_ALLMT];
             R->used_frag = H->misc[M_USEDFRAG];
             R->used_mt = used;
@@ -750,6 +818,7 @@ __global__ __launch_bounds__(BLOCK) void k_call_loci(
         const uint32_t* src = (const uint32_t*)rowst;
         uint32_t* dst = (uint32_t*)out;
         for (int i = tid; i < (int)(sizeof(smc_row) / 4); i += BLOCK) dst[i] = src[i];
+        STAMP(7);
     }
 }
 
@@ -857,7 +926,7 @@ struct smc_ctx {
 };
 
 static size_t host_hdr_bytes(int a_cap) {
-    return sizeof(Hdr) + (size_t)a_cap * SMC_NT * 4 + (size_t)a_cap * 8 + (size_t)a_cap * 4 + (size_t)a_cap * 4 + sizeof(smc_row);
+    return sizeof(Hdr) + (size_t)a_cap * SMC_NT * 4 + (size_t)a_cap * 8 + (size_t)a_cap * 4 + (size_t)a_cap * 4 + sizeof(smc_row) + 128 * 8;
 }
 static size_t table_bytes(const smc_locus& L) {
     size_t b = 4 * ((size_t)L.n_umi + 1) + 8 * (size_t)L.n_frag + (size_t)L.n_umi;
@@ -1121,6 +1190,17 @@ int smc_call_batch_host(smc_ctx* ctx, const smc_params* prm, const smc_locus* lo
     cleanup();
     return rc;
 }
+
+#ifdef SMC_STAMPS
+int smc_debug_stamps(unsigned long long* out, int reset) {
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16));
+    if (reset) {
+        unsigned long long z[16] = {0};
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z));
+    }
+    return SMC_OK;
+}
+#endif
 
 int smc_event_create(void** ev) {
     hipEvent_t e;

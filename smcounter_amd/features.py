@@ -6,7 +6,9 @@ planes, 16 bytes per pileup read, every locus's reads contiguous and starting on
 
     meta[i] = allele | bq << 8 | flags << 16 | mq << 24
     umi[i]  = barcode index within the locus
-    frag[i] = fragment index within the barcode
+    frag[i] = fragment slot within the locus: fragments of barcode u occupy the contiguous slots
+              [sum of fragment counts of barcodes < u, ...), in order of first appearance within
+              the barcode (= the index of the readid in allBcDict[BC], smCounter.py:463-464)
     dist[i] = distToBcEnd | distToPrimerEnd << 16        (regular bases only, saturated)
 
 flags: bit0 pairOrder is R2 (smCounter.py:359-362, carried over from the previous read when a
@@ -136,13 +138,22 @@ def extract_features(pb: PileupBatch, params: VcParams) -> DeviceBatch:
     loci = np.zeros(n_loci, LOCUS_DTYPE)
     n_umi = np.zeros(n_loci, np.int64)
     n_frag = np.zeros(n_loci, np.int64)
+    slot = np.zeros(n, np.uint32)
     if n:
         np.maximum.at(n_umi, locus_of, pb.umi.astype(np.int64) + 1)
-        ukey = locus_of * (int(n_umi.max()) + 1) + pb.umi.astype(np.int64)
-        uk, inv = np.unique(ukey, return_inverse=True)
+        um = int(n_umi.max()) + 1
+        ukey = locus_of * um + pb.umi.astype(np.int64)
+        uk, inv = np.unique(ukey, return_inverse=True)           # sorted: by locus, then barcode
         fmax = np.zeros(len(uk), np.int64)
         np.maximum.at(fmax, inv, pb.frag.astype(np.int64) + 1)
-        np.add.at(n_frag, uk // (int(n_umi.max()) + 1), fmax)
+        kl = uk // um
+        np.add.at(n_frag, kl, fmax)
+        excl = np.cumsum(fmax) - fmax                            # exclusive, over all loci
+        locus_first = np.zeros(n_loci, np.int64)
+        first_key = np.concatenate([[True], kl[1:] != kl[:-1]])
+        locus_first[kl[first_key]] = excl[first_key]
+        base_local = excl - locus_first[kl]
+        slot = (base_local[inv] + pb.frag.astype(np.int64)).astype(np.uint32)
 
     # --- padded CSR: each locus starts on a READ_ALIGN boundary
     padded = (lens + READ_ALIGN - 1) // READ_ALIGN * READ_ALIGN
@@ -175,6 +186,6 @@ def extract_features(pb: PileupBatch, params: VcParams) -> DeviceBatch:
                 mask |= 1 << a
         loci["snp_mask"][l] = mask
 
-    return DeviceBatch(loci=loci, meta=plane(meta), umi=plane(pb.umi), frag=plane(pb.frag),
+    return DeviceBatch(loci=loci, meta=plane(meta), umi=plane(pb.umi), frag=plane(slot),
                        dist=plane(dist), chrom=list(pb.chrom), pos=pb.pos.copy(),
                        ref=list(pb.ref), alleles=[list(t) for t in pb.alleles])

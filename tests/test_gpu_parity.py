@@ -20,8 +20,8 @@ P_TOL = 1e-6
 def test_golden_rows_vs_oracle_and_reference(engine0, path):
     pb, db, P, refp, expected = load_golden(path)
     got = engine0.call_batch_host(db, P)
-    want = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE)
-    assert abi.compare_rows(got, want, PI_TOL, P_TOL) == []
+    want, fragile = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE, return_fragile=True)
+    assert abi.compare_rows(got, want, PI_TOL, P_TOL, fragile) == []
     text = rows.format_rows(got, db, P, refp)
     ties = abi.near_tie_loci(got, want)
     for l, (t, e) in enumerate(zip(text, expected)):
@@ -42,8 +42,9 @@ def test_synthetic_configs_vs_oracle(engine0, name, n):
     planes = engine0.upload(db)
     plan = engine0.make_plan(db.loci)
     got = plan.download(plan.run(planes, P))
-    want = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE)
-    assert abi.compare_rows(got, want, PI_TOL, P_TOL) == []
+    want, fragile = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE, return_fragile=True)
+    assert (fragile > 0).mean() <= 0.01          # realistic error rates: rounding-decided barcodes are rare
+    assert abi.compare_rows(got, want, PI_TOL, P_TOL, fragile) == []
     assert float(np.abs(got["pi"] - want["pi"]).max()) <= PI_TOL
     # run-to-run bit reproducibility (fixed-point PI accumulation, no float atomics)
     again = plan.download(plan.run(planes, P))
@@ -62,8 +63,8 @@ def test_stress_mix_of_sizes_and_bins(engine0):
     P = VcParams(mtDepth=5000, rpb=3.0, hpLen=8, mtDrop=1)
     db = features.extract_features(pb, P)
     got = engine0.call_batch_host(db, P)
-    want = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE)
-    assert abi.compare_rows(got, want, PI_TOL, P_TOL) == []
+    want, fragile = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE, return_fragile=True)
+    assert abi.compare_rows(got, want, PI_TOL, P_TOL, fragile) == []
 
 
 def test_huge_locus_uses_global_tables(engine0):
@@ -73,8 +74,8 @@ def test_huge_locus_uses_global_tables(engine0):
     db = synth.generate_native(cfg, 0, 2, P)
     assert 8 * int(db.loci["n_frag"][0]) > 160 * 1024
     got = engine0.call_batch_host(db, P)
-    want = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE)
-    assert abi.compare_rows(got, want, PI_TOL, P_TOL) == []
+    want, fragile = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE, return_fragile=True)
+    assert abi.compare_rows(got, want, PI_TOL, P_TOL, fragile) == []
 
 
 def test_triple_alignment_fragments(engine0):
@@ -84,8 +85,8 @@ def test_triple_alignment_fragments(engine0):
     P = VcParams(mtDepth=500, rpb=4.0, hpLen=8, minBQ=2, minMQ=0, mismatchThr=100.0)
     db = features.extract_features(pb, P)
     got = engine0.call_batch_host(db, P)
-    want = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE)
-    assert abi.compare_rows(got, want, PI_TOL, P_TOL) == []
+    want, fragile = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE, return_fragile=True)
+    assert abi.compare_rows(got, want, PI_TOL, P_TOL, fragile) == []
 
 
 def test_downsample_flag_and_empty_batch(engine0):

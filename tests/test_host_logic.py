@@ -59,12 +59,20 @@ def test_feature_extraction_matches_native_generator():
             seen = {}
             for x in ff:
                 seen.setdefault(int(x), len(seen))
-            assert list(seen.keys()) == list(range(len(seen)))
+            # fragment slots: barcode-major, contiguous, in order of first appearance
+            assert list(seen.keys()) == list(range(tot, tot + len(seen)))
             tot += len(seen)
         assert tot == db.loci["n_frag"][l]
     pb = synth.generate(cfg, 0, 20)
     db2 = features.extract_features(pb, synth.params_for(cfg))
     assert (db2.loci["n_umi"] == cfg.n_umi).all() and db2.n_reads == 20 * cfg.depth
+    for l in range(db2.n_loci):
+        o, n = int(db2.loci["read_off"][l]), int(db2.loci["n_reads"][l])
+        s_ = pb.locus_slice(l)
+        u, fl, slot = pb.umi[s_], pb.frag[s_], db2.frag[o:o + n]
+        nfr = [int(fl[u == uu].max()) + 1 for uu in range(int(u.max()) + 1)]
+        base = np.concatenate([[0], np.cumsum(nfr)])
+        assert (slot == base[u] + fl).all() and base[-1] == db2.loci["n_frag"][l]
 
 
 def test_unflagged_first_read_is_an_error():
