@@ -180,16 +180,26 @@ __device__ __forceinline__ double pcr_of(int cnt, double denom) { return exp10(-
 // ------------------------------------------------------------------------------------------
 // kernel 1: scan + group + score + rank
 // ------------------------------------------------------------------------------------------
+#ifndef SMC_ABLATE
+#define SMC_ABLATE 0   // diagnostic builds: return after phase N (timing only, rows are garbage)
+#endif
+#ifndef SMC_G_FRAGS
+#define SMC_G_FRAGS 24
+#endif
+#ifndef SMC_WAVES_PER_EU
+#define SMC_WAVES_PER_EU 4
+#endif
 template <int BLOCK, bool GLOBAL_TABLES>
-__global__ __launch_bounds__(BLOCK) void k_call_loci(
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES_PER_EU, 8))) void k_call_loci(
     KParams P, const smc_locus* __restrict__ loci, const int* __restrict__ order, int a_cap,
     const uint32_t* __restrict__ g_meta, const uint32_t* __restrict__ g_umi, const uint32_t* __restrict__ g_frag,
     const uint32_t* __restrict__ g_dist, const double* __restrict__ g_lut, smc_row* __restrict__ rows,
     uint8_t* __restrict__ scratch, const int64_t* __restrict__ scratch_off) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // `loci` is this bin's descriptor array in launch order; order[] maps back to the batch index
+    const smc_locus L = loci[blockIdx.x];
     const int li = order[blockIdx.x];
-    const smc_locus L = loci[li];
     const int n = L.n_reads, nU = L.n_umi, nF = L.n_frag, nA = L.n_alleles;
     const uint4* meta4 = (const uint4*)(g_meta + L.read_off);
     const uint4* umi4 = (const uint4*)(g_umi + L.read_off);
@@ -211,6 +221,10 @@ __global__ __launch_bounds__(BLOCK) void k_call_loci(
     unsigned char* umi_flag = (unsigned char*)(fmax + nF);            // [nU]
 
     STAMP_INIT();
+    // first step's reads are requested before the LDS image is initialised (HBM latency overlaps it)
+    const int n4 = (n + 3) >> 2;
+    uint4 m4, u4, f4, d4;
+    if (tid < n4) { m4 = meta4[tid]; u4 = umi4[tid]; f4 = frag4[tid]; d4 = dist4[tid]; }
     // ---- S0: init
     {
         uint32_t* z = (uint32_t*)smem;
@@ -223,23 +237,19 @@ __global__ __launch_bounds__(BLOCK) void k_call_loci(
     }
     __syncthreads();
     STAMP(0);
+    if (SMC_ABLATE == 1) return;
 
     // ---- P1: ONE pass over the reads, 4 reads per lane per step (16-byte loads of each plane):
     // inclusion test and tallies (smCounter.py:368-460), first slot of each barcode, which barcodes
     // enter bcDict (:467-468), and per fragment the smallest / largest key of its included reads.
+    // Tallies of the locus's reference allele (nearly every read) are kept in per-lane registers and
+    // reduced once; other alleles are aggregated per wave step with ballots, only when present.
     {
-        uint32_t acc[4][9];   // wave-uniform (SGPR) tallies of A,T,G,C
+        uint32_t accv[9];
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int k = 0; k < 9; ++k) acc[a][k] = 0;
-        uint32_t n_inc_w = 0, err_w = 0;
-        const int n4 = (n + 3) >> 2;
-        uint4 m4, u4, f4, d4;
-        {
-            const int q = tid;
-            if (q < n4) { m4 = meta4[q]; u4 = umi4[q]; f4 = frag4[q]; d4 = dist4[q]; }
-        }
+        for (int k = 0; k < 9; ++k) accv[k] = 0;
+        uint32_t n_inc_l = 0, err_l = 0;
+        const int refa = L.ref_allele;
         for (int qb = 0; qb < n4; qb += BLOCK) {
             const int q = qb + tid;
             const uint4 cm = m4, cu = u4, cf = f4, cd = d4;
@@ -252,54 +262,58 @@ __global__ __launch_bounds__(BLOCK) void k_call_loci(
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int i = 4 * q + k;
-                const bool valid = q < n4 && i < n;
+                const bool valid = i < n;                               // n4 = ceil(n/4): q < n4 follows
                 const uint32_t u = us[k], f = fs[k];
                 ReadRec r = decode_read(ms[k], ds[k], P);
                 const bool ok = valid && u < (uint32_t)nU && f < (uint32_t)nF && r.allele < nA;
-                if (__ballot(valid && !ok)) err_w = 1;
+                err_l |= (uint32_t)(valid && !ok);
                 const bool inc = ok && r.inc;
                 const bool regular = r.kind == SMC_KIND_BASE;
                 const bool r1i = inc && regular && !r.r2, r2i = inc && regular && r.r2;
-                const unsigned long long b_fwd = __ballot(ok && r.kind != SMC_KIND_GAP && !r.rev);
-                const unsigned long long b_rev = __ballot(ok && r.kind != SMC_KIND_GAP && r.rev);
-                const unsigned long long b_lowq = __ballot(ok && r.lowq);
-                const unsigned long long b_r1n = __ballot(r1i);
-                const unsigned long long b_r1le = __ballot(r1i && r.dbc <= 20);
-                const unsigned long long b_r2n = __ballot(r2i);
-                const unsigned long long b_r2bc = __ballot(r2i && r.dbc <= 20);
-                const unsigned long long b_r2pr = __ballot(r2i && r.dpr <= P.primer_dist);
-                n_inc_w += __popcll(__ballot(inc));
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    const unsigned long long ma = __ballot(ok && r.allele == a);
-                    if (ma) {
-                        acc[a][SMC_T_CNT] += __popcll(ma);
-                        acc[a][SMC_T_FWD] += __popcll(ma & b_fwd);
-                        acc[a][SMC_T_REV] += __popcll(ma & b_rev);
-                        acc[a][SMC_T_LOWQ] += __popcll(ma & b_lowq);
-                        acc[a][SMC_T_R1N] += __popcll(ma & b_r1n);
-                        acc[a][SMC_T_R1LE] += __popcll(ma & b_r1le);
-                        acc[a][SMC_T_R2N] += __popcll(ma & b_r2n);
-                        acc[a][SMC_T_R2BCLE] += __popcll(ma & b_r2bc);
-                        acc[a][SMC_T_R2PRLE] += __popcll(ma & b_r2pr);
-                    }
-                }
-                if (ok && r.allele >= 4) {   // rare alleles: straight LDS atomics
-                    uint32_t* t = tal + r.allele * SMC_NT;
-                    atomicAdd(&t[SMC_T_CNT], 1u);
-                    if (r.kind != SMC_KIND_GAP) atomicAdd(&t[r.rev ? SMC_T_REV : SMC_T_FWD], 1u);
-                    if (r.lowq) atomicAdd(&t[SMC_T_LOWQ], 1u);
-                    if (r1i) { atomicAdd(&t[SMC_T_R1N], 1u); if (r.dbc <= 20) atomicAdd(&t[SMC_T_R1LE], 1u); }
-                    if (r2i) {
-                        atomicAdd(&t[SMC_T_R2N], 1u);
-                        if (r.dbc <= 20) atomicAdd(&t[SMC_T_R2BCLE], 1u);
-                        if (r.dpr <= P.primer_dist) atomicAdd(&t[SMC_T_R2PRLE], 1u);
+                const bool e_fwd = r.kind != SMC_KIND_GAP && !r.rev, e_rev = r.kind != SMC_KIND_GAP && r.rev;
+                const bool e_r1le = r1i && r.dbc <= 20, e_r2bc = r2i && r.dbc <= 20, e_r2pr = r2i && r.dpr <= P.primer_dist;
+                n_inc_l += (uint32_t)inc;
+                const bool is_ref = ok && r.allele == refa;
+                accv[SMC_T_CNT] += (uint32_t)is_ref;
+                accv[SMC_T_FWD] += (uint32_t)(is_ref && e_fwd);
+                accv[SMC_T_REV] += (uint32_t)(is_ref && e_rev);
+                accv[SMC_T_LOWQ] += (uint32_t)(is_ref && r.lowq);
+                accv[SMC_T_R1N] += (uint32_t)(is_ref && r1i);
+                accv[SMC_T_R1LE] += (uint32_t)(is_ref && e_r1le);
+                accv[SMC_T_R2N] += (uint32_t)(is_ref && r2i);
+                accv[SMC_T_R2BCLE] += (uint32_t)(is_ref && e_r2bc);
+                accv[SMC_T_R2PRLE] += (uint32_t)(is_ref && e_r2pr);
+                unsigned long long nr = __builtin_amdgcn_ballot_w64(ok && !is_ref);
+                if (nr) {                                               // wave-uniform, rare
+                    const unsigned long long b_fwd = __builtin_amdgcn_ballot_w64(e_fwd), b_rev = __builtin_amdgcn_ballot_w64(e_rev);
+                    const unsigned long long b_lowq = __builtin_amdgcn_ballot_w64(r.lowq);
+                    const unsigned long long b_r1n = __builtin_amdgcn_ballot_w64(r1i), b_r1le = __builtin_amdgcn_ballot_w64(e_r1le);
+                    const unsigned long long b_r2n = __builtin_amdgcn_ballot_w64(r2i), b_r2bc = __builtin_amdgcn_ballot_w64(e_r2bc);
+                    const unsigned long long b_r2pr = __builtin_amdgcn_ballot_w64(e_r2pr);
+                    while (nr) {
+                        const int src = __ffsll((long long)nr) - 1;
+                        const int a0 = __builtin_amdgcn_readlane(r.allele, src);
+                        const unsigned long long ma = __builtin_amdgcn_ballot_w64(ok && r.allele == a0);
+                        nr &= ~ma;
+                        if (lane == 0) {
+                            uint32_t* t = tal + a0 * SMC_NT;
+                            uint32_t c;
+                            atomicAdd(&t[SMC_T_CNT], (uint32_t)__popcll(ma));
+                            if ((c = __popcll(ma & b_fwd))) atomicAdd(&t[SMC_T_FWD], c);
+                            if ((c = __popcll(ma & b_rev))) atomicAdd(&t[SMC_T_REV], c);
+                            if ((c = __popcll(ma & b_lowq))) atomicAdd(&t[SMC_T_LOWQ], c);
+                            if ((c = __popcll(ma & b_r1n))) atomicAdd(&t[SMC_T_R1N], c);
+                            if ((c = __popcll(ma & b_r1le))) atomicAdd(&t[SMC_T_R1LE], c);
+                            if ((c = __popcll(ma & b_r2n))) atomicAdd(&t[SMC_T_R2N], c);
+                            if ((c = __popcll(ma & b_r2bc))) atomicAdd(&t[SMC_T_R2BCLE], c);
+                            if ((c = __popcll(ma & b_r2pr))) atomicAdd(&t[SMC_T_R2PRLE], c);
+                        }
                     }
                 }
                 if (ok) {
-                    atomicMin(&umi_base[u], f);
+                    if (umi_base[u] > f) atomicMin(&umi_base[u], f);     // converges after a few reads
                     if (inc) {
-                        umi_flag[u] = 1;
+                        if (!umi_flag[u]) umi_flag[u] = 1;
                         const uint32_t key = make_key(i, r.allele, r.bq_eff);
                         atomicMin(&fmin[f], key);
                         atomicMax(&fmax[f], key);
@@ -307,18 +321,18 @@ __global__ __launch_bounds__(BLOCK) void k_call_loci(
                 }
             }
         }
-        if (lane == 0) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int k = 0; k < 9; ++k)
-                    if (acc[a][k]) atomicAdd(&tal[a * SMC_NT + k], acc[a][k]);
-            if (n_inc_w) atomicAdd(&H->misc[M_NINC], n_inc_w);
-            if (err_w) H->misc[M_ERR] = 1;
+        for (int k = 0; k < 9; ++k) {
+            const uint32_t v = (uint32_t)wave_reduce_add((int)accv[k], WAVE);
+            if (lane == 0 && v && refa < nA) atomicAdd(&tal[refa * SMC_NT + k], v);
         }
+        const uint32_t ni = (uint32_t)wave_reduce_add((int)n_inc_l, WAVE);
+        if (lane == 0 && ni) atomicAdd(&H->misc[M_NINC], ni);
+        if (__builtin_amdgcn_ballot_w64(err_l != 0) && lane == 0) H->misc[M_ERR] = 1;
     }
     __syncthreads();
     STAMP(1);
+    if (SMC_ABLATE == 2) return;
 
     // ---- S2: barcode bookkeeping: allMT (:482), size of bcDict, slot ranges must be ordered
     {
@@ -331,7 +345,7 @@ __global__ __launch_bounds__(BLOCK) void k_call_loci(
         }
         nbc = wave_reduce_add((int)nbc, WAVE);
         allmt = wave_reduce_add((int)allmt, WAVE);
-        if (__ballot(bad != 0) && lane == 0) H->misc[M_ERR] = 1;
+        if (__builtin_amdgcn_ballot_w64(bad != 0) && lane == 0) H->misc[M_ERR] = 1;
         if (lane == 0) { atomicAdd(&H->misc[M_NBC], nbc); atomicAdd(&H->misc[M_ALLMT], allmt); }
     }
     __syncthreads();
@@ -393,11 +407,11 @@ __global__ __launch_bounds__(BLOCK) void k_call_loci(
                 if (!marked) fmin[s] = st;
             }
             // concordant / discordant pair tallies: wave-aggregated for A,T,G,C
-            const unsigned long long bc = __ballot(conc), bd = __ballot(disc);
+            const unsigned long long bc = __builtin_amdgcn_ballot_w64(conc), bd = __builtin_amdgcn_ballot_w64(disc);
             if (bc | bd) {
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
-                    const unsigned long long ma = __ballot((conc || disc) && ev_allele == a);
+                    const unsigned long long ma = __builtin_amdgcn_ballot_w64((conc || disc) && ev_allele == a);
                     if (ma && lane == 0) {
                         const int nc = __popcll(ma & bc), nd = __popcll(ma & bd);
                         if (nc) atomicAdd(&tal[a * SMC_NT + SMC_T_CONCORD], (uint32_t)nc);
@@ -417,6 +431,7 @@ __global__ __launch_bounds__(BLOCK) void k_call_loci(
     }
     __syncthreads();
     STAMP(4);
+    if (SMC_ABLATE == 3) return;
     if (H->misc[M_RESOLVED] != H->misc[M_NINC]) {
         // Some read name has >= 3 included alignments on this locus (rare): redo the fragment table,
         // mark those fragments, resolve the others as above and replay the marked ones in read order.
@@ -496,8 +511,10 @@ __global__ __launch_bounds__(BLOCK) void k_call_loci(
     // ---- U: per-barcode posterior (calProb, :26-98) and PI / consensus accumulation (:506-532)
     {
         // lanes per barcode: power of two, enough groups to cover the barcodes
+        // (a function of the locus only, so results do not depend on the launch shape): one lane
+        // walks up to ~48 fragments
         int G = 1;
-        while (G < WAVE && (BLOCK / (G * 2)) >= nU) G <<= 1;
+        while (G < WAVE && G < BLOCK && (long long)nF > (long long)SMC_G_FRAGS * G * nU) G <<= 1;
         const int grp = tid / G, j = tid % G, ngrp = BLOCK / G;
         // fixed-point scale of the PI sums: order-independent, hence bit-reproducible
         int bits = 32 - __clz(used);
@@ -749,6 +766,7 @@ __global__ __launch_bounds__(BLOCK) void k_call_loci(
         }
         __syncthreads();
         STAMP(6);
+        if (SMC_ABLATE == 4) return;
 
         // ---- E: ranking and candidates (:534-555), one thread
         if (tid == 0) {
@@ -933,12 +951,17 @@ static size_t table_bytes(const smc_locus& L) {
     return (b + 15) & ~(size_t)15;
 }
 
+#ifndef SMC_CLS1_BLOCK
+#define SMC_CLS1_BLOCK 128
+#endif
+
 struct Bin {
     int cls;              // 0: 64 thr, 1: 256, 2: 512, 3: 1024 (LDS tables), 4: 1024 (global tables)
     int a_cap;
     size_t lds_bytes;
     std::vector<int> order;
     int* d_order = nullptr;
+    smc_locus* d_loci = nullptr;   // descriptors in launch order
     int64_t* d_scratch_off = nullptr;
     uint8_t* d_scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -964,7 +987,7 @@ static hipError_t launch_bin(const Bin& b, const KParams& kp, const smc_plan* p,
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b.lds_bytes);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)b.order.size()), dim3(BLOCK), b.lds_bytes, st, kp, p->d_loci, b.d_order, b.a_cap,
+    hipLaunchKernelGGL(kern, dim3((unsigned)b.order.size()), dim3(BLOCK), b.lds_bytes, st, kp, b.d_loci, b.d_order, b.a_cap,
                        meta, umi, frag, dist, p->ctx->lut, rows, b.d_scratch, b.d_scratch_off);
     return hipGetLastError();
 }
@@ -1018,6 +1041,7 @@ void smc_plan_destroy(smc_plan* p) {
     for (auto e : p->ev1) (void)hipEventDestroy(e);
     for (auto& b : p->bins) {
         (void)hipFree(b.d_order);
+        (void)hipFree(b.d_loci);
         (void)hipFree(b.d_scratch_off);
         (void)hipFree(b.d_scratch);
     }
@@ -1070,6 +1094,12 @@ int smc_plan_create(smc_ctx* ctx, const smc_locus* loci, int64_t n_loci, smc_pla
         b.lds_bytes = (b.lds_bytes + 255) & ~(size_t)255;
         HIPCHK(hipMalloc(&b.d_order, sizeof(int) * b.order.size()));
         HIPCHK(hipMemcpy(b.d_order, b.order.data(), sizeof(int) * b.order.size(), hipMemcpyHostToDevice));
+        {
+            std::vector<smc_locus> perm(b.order.size());
+            for (size_t k = 0; k < b.order.size(); ++k) perm[k] = loci[b.order[k]];
+            HIPCHK(hipMalloc(&b.d_loci, sizeof(smc_locus) * perm.size()));
+            HIPCHK(hipMemcpy(b.d_loci, perm.data(), sizeof(smc_locus) * perm.size(), hipMemcpyHostToDevice));
+        }
         if (b.cls == 4) {
             HIPCHK(hipMalloc(&b.d_scratch_off, sizeof(int64_t) * soff.size()));
             HIPCHK(hipMemcpy(b.d_scratch_off, soff.data(), sizeof(int64_t) * soff.size(), hipMemcpyHostToDevice));
@@ -1143,7 +1173,7 @@ int smc_plan_run(smc_plan* p, const smc_params* prm, const uint32_t* meta, const
         hipError_t e = hipSuccess;
         switch (b.cls) {
             case 0: e = launch_bin<64, false>(b, kp, p, meta, umi, frag, dist, rows, st); break;
-            case 1: e = launch_bin<256, false>(b, kp, p, meta, umi, frag, dist, rows, st); break;
+            case 1: e = launch_bin<SMC_CLS1_BLOCK, false>(b, kp, p, meta, umi, frag, dist, rows, st); break;
             case 2: e = launch_bin<512, false>(b, kp, p, meta, umi, frag, dist, rows, st); break;
             case 3: e = launch_bin<1024, false>(b, kp, p, meta, umi, frag, dist, rows, st); break;
             default: e = launch_bin<1024, true>(b, kp, p, meta, umi, frag, dist, rows, st); break;

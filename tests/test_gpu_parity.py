@@ -25,8 +25,8 @@ def test_golden_rows_vs_oracle_and_reference(engine0, path):
     text = rows.format_rows(got, db, P, refp)
     ties = abi.near_tie_loci(got, want)
     for l, (t, e) in enumerate(zip(text, expected)):
-        if e["tie_ambiguous"] or l in ties:
-            continue
+        if e["tie_ambiguous"] or l in ties or fragile[l]:
+            continue        # unpinned by the reference algorithm itself (see abi.compare_rows)
         assert t == e["row"], "locus %d differs from the reference's own output" % l
         if e["pi_raw"]:
             d = max(max(abs(e["pi_raw"][k] - got["pi"][l][k]) for k in range(4)),
