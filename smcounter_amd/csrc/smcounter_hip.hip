@@ -175,7 +175,14 @@ __device__ __forceinline__ ReadRec decode_read(uint32_t m, uint32_t d, const KPa
 // ties between alleles stay exact).
 __device__ __forceinline__ double pcr_of(int cnt, double denom) { return exp10(-6.0 * ((cnt + 0.5) / denom)); }
 
-#define LUT_N 128   // qualities with an LDS-resident error probability; rarer ones read the global table
+#define LUT_N 128
+// Predicates are kept as 64-bit lane masks: a ballot of a single compare is one v_cmp into an SGPR
+// pair, combinations are scalar ANDs, "counter += predicate" is one v_addc_co_u32 with the mask as
+// carry-in, and a branch on a mask is s_and_saveexec (inverse ballot) - no per-lane 0/1 integers.
+typedef unsigned long long lmask;
+#define BAL(x) __builtin_amdgcn_ballot_w64(x)
+#define LANES(m) __builtin_amdgcn_inverse_ballot_w64(m)
+#define ADDM(acc, m) asm volatile("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(acc) : "s"((lmask)(m)) : "vcc")   // qualities with an LDS-resident error probability; rarer ones read the global table
 
 // ------------------------------------------------------------------------------------------
 // kernel 1: scan + group + score + rank
@@ -243,13 +250,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
     // inclusion test and tallies (smCounter.py:368-460), first slot of each barcode, which barcodes
     // enter bcDict (:467-468), and per fragment the smallest / largest key of its included reads.
     // Tallies of the locus's reference allele (nearly every read) are kept in per-lane registers and
-    // reduced once; other alleles are aggregated per wave step with ballots, only when present.
+    // reduced once; other alleles are aggregated per wave step, only when present.
     {
         uint32_t accv[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) accv[k] = 0;
-        uint32_t n_inc_l = 0, err_l = 0;
-        const int refa = L.ref_allele;
+        uint32_t n_inc_s = 0;
+        lmask err_m = 0;
+        const uint32_t refa = L.ref_allele;
         for (int qb = 0; qb < n4; qb += BLOCK) {
             const int q = qb + tid;
             const uint4 cm = m4, cu = u4, cf = f4, cd = d4;
@@ -262,59 +270,58 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int i = 4 * q + k;
-                const bool valid = i < n;                               // n4 = ceil(n/4): q < n4 follows
-                const uint32_t u = us[k], f = fs[k];
-                ReadRec r = decode_read(ms[k], ds[k], P);
-                const bool ok = valid && u < (uint32_t)nU && f < (uint32_t)nF && r.allele < nA;
-                err_l |= (uint32_t)(valid && !ok);
-                const bool inc = ok && r.inc;
-                const bool regular = r.kind == SMC_KIND_BASE;
-                const bool r1i = inc && regular && !r.r2, r2i = inc && regular && r.r2;
-                const bool e_fwd = r.kind != SMC_KIND_GAP && !r.rev, e_rev = r.kind != SMC_KIND_GAP && r.rev;
-                const bool e_r1le = r1i && r.dbc <= 20, e_r2bc = r2i && r.dbc <= 20, e_r2pr = r2i && r.dpr <= P.primer_dist;
-                n_inc_l += (uint32_t)inc;
-                const bool is_ref = ok && r.allele == refa;
-                accv[SMC_T_CNT] += (uint32_t)is_ref;
-                accv[SMC_T_FWD] += (uint32_t)(is_ref && e_fwd);
-                accv[SMC_T_REV] += (uint32_t)(is_ref && e_rev);
-                accv[SMC_T_LOWQ] += (uint32_t)(is_ref && r.lowq);
-                accv[SMC_T_R1N] += (uint32_t)(is_ref && r1i);
-                accv[SMC_T_R1LE] += (uint32_t)(is_ref && e_r1le);
-                accv[SMC_T_R2N] += (uint32_t)(is_ref && r2i);
-                accv[SMC_T_R2BCLE] += (uint32_t)(is_ref && e_r2bc);
-                accv[SMC_T_R2PRLE] += (uint32_t)(is_ref && e_r2pr);
-                unsigned long long nr = __builtin_amdgcn_ballot_w64(ok && !is_ref);
+                const uint32_t mw = ms[k], u = us[k], f = fs[k], dw = ds[k];
+                const uint32_t a = mw & 0xffu, kind = (mw >> 19) & 3u;
+                const lmask m_valid = BAL(i < n);                         // n4 = ceil(n/4): q < n4 follows
+                const lmask m_ok = m_valid & BAL(u < (uint32_t)nU) & BAL(f < (uint32_t)nF) & BAL(a < (uint32_t)nA);
+                err_m |= m_valid & ~m_ok;
+                const lmask m_base = BAL(kind == SMC_KIND_BASE), m_gap = BAL(kind == SMC_KIND_GAP);
+                const lmask m_qok = BAL((int)((mw >> 8) & 0xffu) >= P.min_bq);            // :378 first term / :428
+                const lmask m_inc = m_ok & (m_qok | m_gap) & BAL((int)(mw >> 24) >= P.min_mq) & BAL((mw & 0x40000u) != 0u);
+                const lmask m_r2 = BAL((mw & 0x10000u) != 0u), m_rev = BAL((mw & 0x20000u) != 0u);
+                const lmask m_ref = m_ok & BAL(a == refa);
+                const lmask m_ib = m_inc & m_base;
+                const lmask m_r1i = m_ib & ~m_r2, m_r2i = m_ib & m_r2;
+                const lmask m_le20 = BAL((dw & 0xffffu) <= 20u), m_prle = BAL((int)(dw >> 16) <= P.primer_dist);
+                const lmask e_fwd = ~m_gap & ~m_rev, e_rev = ~m_gap & m_rev, e_lowq = m_base & ~m_qok;
+                n_inc_s += (uint32_t)__popcll(m_inc);
+                ADDM(accv[SMC_T_CNT], m_ref);
+                ADDM(accv[SMC_T_FWD], m_ref & e_fwd);
+                ADDM(accv[SMC_T_REV], m_ref & e_rev);
+                ADDM(accv[SMC_T_LOWQ], m_ref & e_lowq);
+                ADDM(accv[SMC_T_R1N], m_ref & m_r1i);
+                ADDM(accv[SMC_T_R1LE], m_ref & m_r1i & m_le20);
+                ADDM(accv[SMC_T_R2N], m_ref & m_r2i);
+                ADDM(accv[SMC_T_R2BCLE], m_ref & m_r2i & m_le20);
+                ADDM(accv[SMC_T_R2PRLE], m_ref & m_r2i & m_prle);
+                lmask nr = m_ok & ~m_ref;
                 if (nr) {                                               // wave-uniform, rare
-                    const unsigned long long b_fwd = __builtin_amdgcn_ballot_w64(e_fwd), b_rev = __builtin_amdgcn_ballot_w64(e_rev);
-                    const unsigned long long b_lowq = __builtin_amdgcn_ballot_w64(r.lowq);
-                    const unsigned long long b_r1n = __builtin_amdgcn_ballot_w64(r1i), b_r1le = __builtin_amdgcn_ballot_w64(e_r1le);
-                    const unsigned long long b_r2n = __builtin_amdgcn_ballot_w64(r2i), b_r2bc = __builtin_amdgcn_ballot_w64(e_r2bc);
-                    const unsigned long long b_r2pr = __builtin_amdgcn_ballot_w64(e_r2pr);
                     while (nr) {
                         const int src = __ffsll((long long)nr) - 1;
-                        const int a0 = __builtin_amdgcn_readlane(r.allele, src);
-                        const unsigned long long ma = __builtin_amdgcn_ballot_w64(ok && r.allele == a0);
+                        const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)a, src);
+                        const lmask ma = m_ok & BAL(a == a0);
                         nr &= ~ma;
                         if (lane == 0) {
                             uint32_t* t = tal + a0 * SMC_NT;
                             uint32_t c;
                             atomicAdd(&t[SMC_T_CNT], (uint32_t)__popcll(ma));
-                            if ((c = __popcll(ma & b_fwd))) atomicAdd(&t[SMC_T_FWD], c);
-                            if ((c = __popcll(ma & b_rev))) atomicAdd(&t[SMC_T_REV], c);
-                            if ((c = __popcll(ma & b_lowq))) atomicAdd(&t[SMC_T_LOWQ], c);
-                            if ((c = __popcll(ma & b_r1n))) atomicAdd(&t[SMC_T_R1N], c);
-                            if ((c = __popcll(ma & b_r1le))) atomicAdd(&t[SMC_T_R1LE], c);
-                            if ((c = __popcll(ma & b_r2n))) atomicAdd(&t[SMC_T_R2N], c);
-                            if ((c = __popcll(ma & b_r2bc))) atomicAdd(&t[SMC_T_R2BCLE], c);
-                            if ((c = __popcll(ma & b_r2pr))) atomicAdd(&t[SMC_T_R2PRLE], c);
+                            if ((c = __popcll(ma & e_fwd))) atomicAdd(&t[SMC_T_FWD], c);
+                            if ((c = __popcll(ma & e_rev))) atomicAdd(&t[SMC_T_REV], c);
+                            if ((c = __popcll(ma & e_lowq))) atomicAdd(&t[SMC_T_LOWQ], c);
+                            if ((c = __popcll(ma & m_r1i))) atomicAdd(&t[SMC_T_R1N], c);
+                            if ((c = __popcll(ma & m_r1i & m_le20))) atomicAdd(&t[SMC_T_R1LE], c);
+                            if ((c = __popcll(ma & m_r2i))) atomicAdd(&t[SMC_T_R2N], c);
+                            if ((c = __popcll(ma & m_r2i & m_le20))) atomicAdd(&t[SMC_T_R2BCLE], c);
+                            if ((c = __popcll(ma & m_r2i & m_prle))) atomicAdd(&t[SMC_T_R2PRLE], c);
                         }
                     }
                 }
-                if (ok) {
+                if (LANES(m_ok)) {
                     if (umi_base[u] > f) atomicMin(&umi_base[u], f);     // converges after a few reads
-                    if (inc) {
+                    if (LANES(m_inc)) {
                         if (!umi_flag[u]) umi_flag[u] = 1;
-                        const uint32_t key = make_key(i, r.allele, r.bq_eff);
+                        const uint32_t bq_eff = LANES(m_gap) ? (uint32_t)P.min_bq : ((mw >> 8) & 0xffu);   // :418
+                        const uint32_t key = ((uint32_t)i << 14) | (a << 8) | bq_eff;
                         atomicMin(&fmin[f], key);
                         atomicMax(&fmax[f], key);
                     }
@@ -324,11 +331,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             const uint32_t v = (uint32_t)wave_reduce_add((int)accv[k], WAVE);
-            if (lane == 0 && v && refa < nA) atomicAdd(&tal[refa * SMC_NT + k], v);
+            if (lane == 0 && v && refa < (uint32_t)nA) atomicAdd(&tal[refa * SMC_NT + k], v);
         }
-        const uint32_t ni = (uint32_t)wave_reduce_add((int)n_inc_l, WAVE);
-        if (lane == 0 && ni) atomicAdd(&H->misc[M_NINC], ni);
-        if (__builtin_amdgcn_ballot_w64(err_l != 0) && lane == 0) H->misc[M_ERR] = 1;
+        if (lane == 0 && n_inc_s) atomicAdd(&H->misc[M_NINC], n_inc_s);
+        if (err_m && lane == 0) H->misc[M_ERR] = 1;
     }
     __syncthreads();
     STAMP(1);
@@ -378,55 +384,45 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
     // ---- R: mate merge (smCounter.py:468-479), assuming every fragment has <= 2 included reads;
     // the count of reads so explained is checked against the number of included reads below.
     auto resolve = [&](bool honour_marks) {
-        uint32_t c = 0;
+        uint32_t c = 0, conc_ref = 0, disc_ref = 0;                      // c is wave-uniform
+        const uint32_t refa = L.ref_allele;
         for (int sb = 0; sb < nF; sb += BLOCK) {
             const int s = sb + tid;
-            bool conc = false, disc = false;
-            int ev_allele = 0;
-            if (s < nF) {
-                const uint32_t a = fmin[s], b = fmax[s];
-                uint32_t st = 0;
-                const bool marked = honour_marks && b == 0xFFFFFFFFu;
-                if (!marked && a != 0xFFFFFFFFu) {
-                    const int a1 = KEY_ALLELE(a), q1 = KEY_BQ(a);
-                    if (a == b) {
-                        st = make_state(a1, q1, false);
-                        c += 1;
-                    } else {
-                        c += 2;
-                        const int a2 = KEY_ALLELE(b), q2 = KEY_BQ(b);
-                        if (a2 == a1 || a2 == N_ID) {
-                            // prob = max(prob_new, prob_old)  <=>  min quality  (:473)
-                            st = make_state(a1, q1 < q2 ? q1 : q2, true);
-                            if (a2 == a1) { conc = true; ev_allele = a1; }
-                        } else {
-                            disc = true; ev_allele = a2;                 // del bcDict[BC][readid] (:478)
-                        }
-                    }
-                }
-                if (!marked) fmin[s] = st;
+            const lmask m_in = BAL(s < nF);
+            uint32_t a = 0xFFFFFFFFu, b = 0u;
+            if (LANES(m_in)) { a = fmin[s]; b = fmax[s]; }
+            const lmask m_marked = honour_marks ? (m_in & BAL(b == 0xFFFFFFFFu)) : 0ull;
+            const lmask m_has = m_in & ~m_marked & BAL(a != 0xFFFFFFFFu);
+            const lmask m_single = m_has & BAL(a == b), m_pair = m_has & ~m_single;
+            const uint32_t a1 = (a >> 8) & 63u, a2 = (b >> 8) & 63u, q1 = a & 255u, q2 = b & 255u;
+            const lmask m_same = BAL(a1 == a2);
+            const lmask m_merge = m_pair & (m_same | BAL(a2 == (uint32_t)N_ID));
+            const lmask m_conc = m_pair & m_same, m_disc = m_pair & ~m_merge;   // :475-476 / :478-479
+            c += (uint32_t)__popcll(m_single) + 2u * (uint32_t)__popcll(m_pair);
+            // state: first read's allele; prob = max(prob_new, prob_old) <=> min quality (:473)
+            uint32_t st = 0u;
+            if (LANES(m_single)) st = ST_PRESENT | (a & 0x3FFFu);
+            if (LANES(m_merge)) st = ST_PRESENT | ST_PAIRED | (a & 0x3F00u) | (q1 < q2 ? q1 : q2);
+            if (LANES(m_in & ~m_marked)) fmin[s] = st;
+            const lmask c_ref = m_conc & BAL(a1 == refa), d_ref = m_disc & BAL(a2 == refa);
+            ADDM(conc_ref, c_ref);
+            ADDM(disc_ref, d_ref);
+            const lmask rare = (m_conc & ~c_ref) | (m_disc & ~d_ref);
+            if (rare) {
+                if (LANES(m_conc & ~c_ref)) atomicAdd(&tal[a1 * SMC_NT + SMC_T_CONCORD], 1u);
+                if (LANES(m_disc & ~d_ref)) atomicAdd(&tal[a2 * SMC_NT + SMC_T_DISCORD], 1u);
             }
-            // concordant / discordant pair tallies: wave-aggregated for A,T,G,C
-            const unsigned long long bc = __builtin_amdgcn_ballot_w64(conc), bd = __builtin_amdgcn_ballot_w64(disc);
-            if (bc | bd) {
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    const unsigned long long ma = __builtin_amdgcn_ballot_w64((conc || disc) && ev_allele == a);
-                    if (ma && lane == 0) {
-                        const int nc = __popcll(ma & bc), nd = __popcll(ma & bd);
-                        if (nc) atomicAdd(&tal[a * SMC_NT + SMC_T_CONCORD], (uint32_t)nc);
-                        if (nd) atomicAdd(&tal[a * SMC_NT + SMC_T_DISCORD], (uint32_t)nd);
-                    }
-                }
-                if ((conc || disc) && ev_allele >= 4)
-                    atomicAdd(&tal[ev_allele * SMC_NT + (conc ? SMC_T_CONCORD : SMC_T_DISCORD)], 1u);
-            }
+        }
+        conc_ref = (uint32_t)wave_reduce_add((int)conc_ref, WAVE);
+        disc_ref = (uint32_t)wave_reduce_add((int)disc_ref, WAVE);
+        if (lane == 0 && refa < (uint32_t)nA) {
+            if (conc_ref) atomicAdd(&tal[refa * SMC_NT + SMC_T_CONCORD], conc_ref);
+            if (disc_ref) atomicAdd(&tal[refa * SMC_NT + SMC_T_DISCORD], disc_ref);
         }
         return c;
     };
     {
-        uint32_t c = resolve(false);
-        c = wave_reduce_add((int)c, WAVE);
+        const uint32_t c = resolve(false);                               // already a per-wave total
         if (lane == 0 && c) atomicAdd(&H->misc[M_RESOLVED], c);
     }
     __syncthreads();
