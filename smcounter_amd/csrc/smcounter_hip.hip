@@ -141,9 +141,13 @@ __device__ __forceinline__ uint32_t make_key(int idx, int allele, int bq) {
 }
 #define KEY_ALLELE(k) (((k) >> 8) & 63u)
 #define KEY_BQ(k) ((k) & 255u)
-// fragment state word (after resolve), kept in fmin[]
+// fragment state word (after resolve), kept in fmin[]: present | allele << 8 | probability index.
+// The index is the merged quality of a 'Paired' fragment (error prob 10^(-q/10)) or PIDX_UNPAIRED
+// for a single read (prob forced to 0.1, smCounter.py:67-68); qualities >= 127 (never produced by
+// a sequencer) take a slow path through the global table.
 #define ST_PRESENT 0x80000000u
 #define ST_PAIRED 0x40000000u
+#define PIDX_UNPAIRED 127u
 __device__ __forceinline__ uint32_t make_state(int allele, int bq, bool paired) {
     return ST_PRESENT | (paired ? ST_PAIRED : 0u) | ((uint32_t)allele << 8) | (uint32_t)bq;
 }
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         uint32_t* z = (uint32_t*)smem;
         const int nz = (int)((sizeof(Hdr) + a_cap * 64 + sizeof(smc_row)) / 4);
         for (int i = tid; i < nz; i += BLOCK) z[i] = 0;
-        for (int i = tid; i < LUT_N; i += BLOCK) lut[i] = g_lut[i];
+        for (int i = tid; i < LUT_N; i += BLOCK) lut[i] = i == (int)PIDX_UNPAIRED ? 0.1 : g_lut[i];
         for (int i = tid; i < nU; i += BLOCK) { umi_base[i] = 0xFFFFFFFFu; umi_flag[i] = 0; }
         for (int i = tid; i < nF; i += BLOCK) { fmin[i] = 0xFFFFFFFFu; fmax[i] = 0u; }
         if (tid == 0) umi_base[nU] = (uint32_t)nF;
@@ -401,7 +405,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
             c += (uint32_t)__popcll(m_single) + 2u * (uint32_t)__popcll(m_pair);
             // state: first read's allele; prob = max(prob_new, prob_old) <=> min quality (:473)
             uint32_t st = 0u;
-            if (LANES(m_single)) st = ST_PRESENT | (a & 0x3FFFu);
+            if (LANES(m_single)) st = ST_PRESENT | (a & 0x3F00u) | PIDX_UNPAIRED;
             if (LANES(m_merge)) st = ST_PRESENT | ST_PAIRED | (a & 0x3F00u) | (q1 < q2 ? q1 : q2);
             if (LANES(m_in & ~m_marked)) fmin[s] = st;
             const lmask c_ref = m_conc & BAL(a1 == refa), d_ref = m_disc & BAL(a2 == refa);
@@ -487,7 +491,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                     }
                 }
             }
-            if (lane == 0) fmin[sb] = present ? make_state(sa, sq, paired) : 0u;
+            if (lane == 0) fmin[sb] = present ? make_state(sa, paired ? sq : (int)PIDX_UNPAIRED, paired) : 0u;
         }
         __syncthreads();
     }
@@ -523,9 +527,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         const double pne = 1.0 - 3e-5;                                 // pcr_no_error, :20
         const int refa = L.ref_allele;
         auto prob_of = [&](uint32_t st) -> double {                    // :65-68
-            if (!(st & ST_PAIRED)) return 0.1;
-            const int q = KEY_BQ(st);
-            return q < LUT_N ? lut[q] : g_lut[q];
+            const uint32_t q = st & 255u;
+            double p = lut[q & (LUT_N - 1)];
+            if (q >= PIDX_UNPAIRED && (st & ST_PAIRED)) p = g_lut[q];   // never taken on real data
+            return p;
         };
 
         for (int u = grp; u < nU; u += ngrp) {
@@ -534,14 +539,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
             // pass A: fragment count, allele set, P(no sequencing error); speculatively also the
             // count and product for the locus's reference allele (the only allele of most barcodes)
             int nf = 0, cnt_ref = 0;
-            uint32_t mlo = 0, mhi = 0;
+            unsigned long long mk = 0;
             double rightP = 1.0, prod_ref = 1.0;
             for (int s = b0 + j; s < b1; s += G) {
                 const uint32_t st = fmin[s];
                 if (st & ST_PRESENT) {
                     ++nf;
                     const int a = KEY_ALLELE(st);
-                    if (a < 32) mlo |= 1u << a; else mhi |= 1u << (a - 32);
+                    mk |= 1ull << a;
                     const double p = prob_of(st), q1 = 1.0 - p;
                     rightP *= q1;
                     const bool same = a == refa;
@@ -551,8 +556,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
             }
             nf = wave_reduce_add(nf, G);
             cnt_ref = wave_reduce_add(cnt_ref, G);
-            mlo = wave_reduce_or(mlo, G);
-            mhi = wave_reduce_or(mhi, G);
+            const uint32_t mlo = wave_reduce_or((uint32_t)mk, G), mhi = wave_reduce_or((uint32_t)(mk >> 32), G);
             rightP = wave_reduce_mul(rightP, G);
             prod_ref = wave_reduce_mul(prod_ref, G);
             const unsigned long long mask = ((unsigned long long)mhi << 32) | mlo;
