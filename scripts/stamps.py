@@ -22,8 +22,8 @@ for _ in range(3):
     plan.run(planes, P, rows)
 torch.cuda.synchronize()
 eng.L.smc_debug_stamps(st, 1)
-v = np.array(list(st)[:8], float)
-names = ["S0 init", "P1 scan+tallies", "S2 umi scan", "P2 frag table", "R1 count", "R2 merge", "U calProb", "E rank+write"]
+v = np.array(list(st)[:10], float)
+names = ["S0 init", "P1 scan", "S2 barcodes", "-", "R merge", "(downsample)", "U0 simple barcodes", "U1 queued barcodes", "-", "E rank+write"]
 for k, nm in enumerate(names):
     print("%-16s %6.1f%%  %8.0f cycles/locus" % (nm, 100 * v[k] / v.sum(), v[k] / (3 * n)))
 print("total %.0f cycles/locus (thread-0 clock64 ticks)" % (v.sum() / (3 * n)))

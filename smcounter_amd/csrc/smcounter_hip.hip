@@ -63,23 +63,29 @@ enum {
     M_TOUCH_LO, M_TOUCH_HI,
     M_CVG,
     M_NEEDFIX,
+    M_NCOMPLEX,   // barcodes deferred to the general calProb path
 };
 
 #ifdef SMC_STAMPS
-// diagnostic build only (scripts/stamps.py): per-phase cycle totals of k_call_loci, thread 0 of each block
+// diagnostic build only (scripts/stamps.py): per-phase cycle totals of k_call_loci, thread 0 of each
+// block; deltas are kept in registers and flushed with one burst of atomics at the very end.
 __device__ unsigned long long g_stamps[16];
+#define STAMP_INIT() unsigned long long t_prev_ = clock64(), t_d_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define STAMP(k)                                                             \
     do {                                                                     \
-        if (threadIdx.x == 0) {                                              \
-            const unsigned long long t_ = clock64();                         \
-            atomicAdd(&g_stamps[k], t_ - t_prev_);                           \
-            t_prev_ = t_;                                                    \
-        }                                                                    \
+        const unsigned long long t_ = clock64();                             \
+        t_d_[k] += t_ - t_prev_;                                             \
+        t_prev_ = t_;                                                        \
     } while (0)
-#define STAMP_INIT() unsigned long long t_prev_ = clock64()
+#define STAMP_FLUSH()                                                        \
+    do {                                                                     \
+        if (threadIdx.x == 0)                                                \
+            for (int k_ = 0; k_ < 12; ++k_) atomicAdd(&g_stamps[k_], t_d_[k_]); \
+    } while (0)
 #else
 #define STAMP(k) do { } while (0)
 #define STAMP_INIT() do { } while (0)
+#define STAMP_FLUSH() do { } while (0)
 #endif
 
 #define NT_K1 11  // tallies kept per allele in LDS: the SMC_T_* of the header, without the pad
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
     KParams P, const smc_locus* __restrict__ loci, const int* __restrict__ order, int a_cap,
     const uint32_t* __restrict__ g_meta, const uint32_t* __restrict__ g_umi, const uint32_t* __restrict__ g_frag,
     const uint32_t* __restrict__ g_dist, const double* __restrict__ g_lut, smc_row* __restrict__ rows,
-    uint8_t* __restrict__ scratch, const int64_t* __restrict__ scratch_off) {
+    uint8_t* __restrict__ scratch, const int64_t* __restrict__ scratch_off, uint32_t* __restrict__ flt_list) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     // `loci` is this bin's descriptor array in launch order; order[] maps back to the batch index
@@ -236,12 +242,19 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
     const int n4 = (n + 3) >> 2;
     uint4 m4, u4, f4, d4;
     if (tid < n4) { m4 = meta4[tid]; u4 = umi4[tid]; f4 = frag4[tid]; d4 = dist4[tid]; }
+    // quality -> error-probability table: requested now, parked in registers, stored to LDS after the
+    // scan (its first reader is the calProb phase), so no phase waits on this load
+    double lut_reg[(LUT_N + BLOCK - 1) / BLOCK];
+#pragma unroll
+    for (int t = 0; t < (LUT_N + BLOCK - 1) / BLOCK; ++t) {
+        const int i = tid + t * BLOCK;
+        lut_reg[t] = i < LUT_N ? g_lut[i] : 0.0;
+    }
     // ---- S0: init
     {
         uint32_t* z = (uint32_t*)smem;
         const int nz = (int)((sizeof(Hdr) + a_cap * 64 + sizeof(smc_row)) / 4);
         for (int i = tid; i < nz; i += BLOCK) z[i] = 0;
-        for (int i = tid; i < LUT_N; i += BLOCK) lut[i] = i == (int)PIDX_UNPAIRED ? 0.1 : g_lut[i];
         for (int i = tid; i < nU; i += BLOCK) { umi_base[i] = 0xFFFFFFFFu; umi_flag[i] = 0; }
         for (int i = tid; i < nF; i += BLOCK) { fmin[i] = 0xFFFFFFFFu; fmax[i] = 0u; }
         if (tid == 0) umi_base[nU] = (uint32_t)nF;
@@ -339,6 +352,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         }
         if (lane == 0 && n_inc_s) atomicAdd(&H->misc[M_NINC], n_inc_s);
         if (err_m && lane == 0) H->misc[M_ERR] = 1;
+#pragma unroll
+        for (int t = 0; t < (LUT_N + BLOCK - 1) / BLOCK; ++t) {
+            const int i = tid + t * BLOCK;
+            if (i < LUT_N) lut[i] = i == (int)PIDX_UNPAIRED ? 0.1 : lut_reg[t];
+        }
     }
     __syncthreads();
     STAMP(1);
@@ -533,35 +551,62 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
             return p;
         };
 
-        for (int u = grp; u < nU; u += ngrp) {
-            if (!umi_flag[u]) continue;                                // not a key of bcDict
-            const int b0 = umi_base[u], b1 = umi_base[u + 1];
+        // pass A of one barcode: fragment count, allele set, P(no sequencing error); speculatively also
+        // the count and product for the locus's reference allele (the only allele of most barcodes)
+        int Gc = G, jc = j;   // lanes per barcode / lane within the group, per phase
+        auto walk = [&](int u, int& b0, int& b1, int& nf, int& cnt_ref, unsigned long long& mask, double& rightP,
+                        double& prod_ref) {
+            b0 = umi_base[u]; b1 = umi_base[u + 1];
             // pass A: fragment count, allele set, P(no sequencing error); speculatively also the
             // count and product for the locus's reference allele (the only allele of most barcodes)
-            int nf = 0, cnt_ref = 0;
+            nf = 0; cnt_ref = 0;
             unsigned long long mk = 0;
-            double rightP = 1.0, prod_ref = 1.0;
-            for (int s = b0 + j; s < b1; s += G) {
-                const uint32_t st = fmin[s];
-                if (st & ST_PRESENT) {
-                    ++nf;
-                    const int a = KEY_ALLELE(st);
-                    mk |= 1ull << a;
-                    const double p = prob_of(st), q1 = 1.0 - p;
-                    rightP *= q1;
-                    const bool same = a == refa;
-                    cnt_ref += same;
-                    prod_ref *= same ? q1 : p;
+            rightP = 1.0; prod_ref = 1.0;
+            {
+                // four slots per lane per step, independent partial products (the walk is a chain of
+                // dependent LDS reads and FP64 multiplies: instruction-level parallelism hides it)
+                double rp[4] = {1.0, 1.0, 1.0, 1.0}, pr[4] = {1.0, 1.0, 1.0, 1.0};
+                for (int s0 = b0 + jc; s0 < b1; s0 += 4 * Gc) {
+                    uint32_t st[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { const int s = s0 + t * Gc; st[t] = s < b1 ? fmin[s] : 0u; }
+                    double pv[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) pv[t] = prob_of(st[t]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const bool present = (st[t] & ST_PRESENT) != 0u;
+                        const int a = KEY_ALLELE(st[t]);
+                        const bool same = a == refa;
+                        const double q1 = 1.0 - pv[t];
+                        nf += present;
+                        cnt_ref += present && same;
+                        mk |= present ? (1ull << a) : 0ull;
+                        rp[t] *= present ? q1 : 1.0;
+                        pr[t] *= present ? (same ? q1 : pv[t]) : 1.0;
+                    }
                 }
+                rightP = (rp[0] * rp[1]) * (rp[2] * rp[3]);
+                prod_ref = (pr[0] * pr[1]) * (pr[2] * pr[3]);
             }
-            nf = wave_reduce_add(nf, G);
-            cnt_ref = wave_reduce_add(cnt_ref, G);
-            const uint32_t mlo = wave_reduce_or((uint32_t)mk, G), mhi = wave_reduce_or((uint32_t)(mk >> 32), G);
-            rightP = wave_reduce_mul(rightP, G);
-            prod_ref = wave_reduce_mul(prod_ref, G);
-            const unsigned long long mask = ((unsigned long long)mhi << 32) | mlo;
-            if (j == 0) { ufrag += nf; c3 += nf >= 3; c5 += nf >= 5; c7 += nf >= 7; c10 += nf >= 10; }
+            nf = wave_reduce_add(nf, Gc);
+            cnt_ref = wave_reduce_add(cnt_ref, Gc);
+            const uint32_t mlo = wave_reduce_or((uint32_t)mk, Gc), mhi = wave_reduce_or((uint32_t)(mk >> 32), Gc);
+            rightP = wave_reduce_mul(rightP, Gc);
+            prod_ref = wave_reduce_mul(prod_ref, Gc);
+            mask = ((unsigned long long)mhi << 32) | mlo;
+        };
 
+        // ---- phase 0: every barcode; those holding only the reference allele (nearly all) are scored
+        // here with straight-line code, the others are queued (fmax[] is dead after the merge)
+        uint32_t* worklist = fmax;
+        for (int u = grp; u < nU; u += ngrp) {
+            if (!umi_flag[u]) continue;                                // not a key of bcDict
+            int b0, b1, nf, cnt_ref;
+            unsigned long long mask;
+            double rightP, prod_ref;
+            walk(u, b0, b1, nf, cnt_ref, mask, rightP, prod_ref);
+            if (j == 0) { ufrag += nf; c3 += nf >= 3; c5 += nf >= 5; c7 += nf >= 7; c10 += nf >= 10; }
             if (nf <= P.mt_drop) {                                     // :28-32 -> all four posteriors 0
                 if (j == 0) {
                     touch_lo |= 0xFu;                                  // finalDict gets A,T,G,C (+ -0.0)
@@ -572,6 +617,64 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                 }
                 continue;
             }
+            if (!(refa < 64 && mask == (1ull << refa))) {
+                if (j == 0) worklist[atomicAdd(&H->misc[M_NCOMPLEX], 1u)] = (uint32_t)u;
+                continue;
+            }
+            // one existing allele (the reference), three padded keys (:49-54): nk = 4
+            const unsigned long long padmask = refa < 4 ? (0xFull & ~(1ull << refa)) : 0x7ull;
+            const double denom = nf + 2.0;                             // :80
+            const double pcr_self = pcr_of(nf, denom), pcr_zero = pcr_of(0, denom);
+            const double tmp0 = pne * prod_ref + rightP * pcr_zero;    // :86
+            const double padOut = rightP * pcr_self;                   // :88-91
+            double sumP = tmp0;
+            sumP += padOut; sumP += padOut; sumP += padOut;
+            const double post0 = sumP <= 0 ? 0.0 : tmp0 / sumP, postp = sumP <= 0 ? 0.0 : padOut / sumP;
+            const double x0 = 1.0 - post0;
+            const double pred0 = x0 > 0.0 ? -log10(x0) : 16.0;         // :508-510
+            // -log10(1 - t) for the padded keys: t is tiny, the series is exact to < 1e-19 below 1e-6
+            double predpad;
+            if (postp < 1e-6) predpad = postp * (1.0 + postp * (0.5 + postp * (1.0 / 3.0))) * 0.43429448190325182765;
+            else { const double xp = 1.0 - postp; predpad = xp > 0.0 ? -log10(xp) : 16.0; }
+            if (j == 0) {
+                const long long fx0 = (long long)(pred0 * fxscale + 0.5), fxp = (long long)(predpad * fxscale + 0.5);
+                if (refa >= 4) atomicAdd(&pifx[refa], (unsigned long long)fx0);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    if (a == refa) pi_acc[a] += fx0;
+                    else if ((padmask >> a) & 1ull) pi_acc[a] += fxp;
+                }
+                const unsigned long long uq = mask | padmask;
+                touch_lo |= (uint32_t)uq; touch_hi |= (uint32_t)(uq >> 32);
+                if (pred0 > predpad) {                                 // unique maximum (:514-519)
+                    const bool str = pred0 > P.smt;
+                    if (refa < 4) {
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) if (a == refa) { mt_acc[a]++; st_acc[a] += str; }
+                    } else { atomicAdd(&mtc[refa], 1u); if (str) atomicAdd(&strong[refa], 1u); }
+                } else if (nf == 1) {                                  // :521-523
+                    if (refa < 4) {
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) if (a == refa) mt_acc[a]++;
+                    } else atomicAdd(&mtc[refa], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        STAMP(6);
+
+        // ---- phase 1: the queued barcodes (more than one allele, or not the reference), general path
+        // (16 lanes per barcode here: few barcodes, so the walks shrink to one or two steps)
+        const int n_complex = (int)H->misc[M_NCOMPLEX];
+        Gc = BLOCK < 16 ? BLOCK : 16;
+        jc = tid % Gc;
+        const int grp1 = tid / Gc, ngrp1 = BLOCK / Gc;
+        for (int w = grp1; w < n_complex; w += ngrp1) {
+            const int u = (int)worklist[w];
+            int b0, b1, nf, cnt_ref;
+            unsigned long long mask;
+            double rightP, prod_ref;
+            walk(u, b0, b1, nf, cnt_ref, mask, rightP, prod_ref);
             const int n_exist = __popcll(mask);
             int npad = n_exist < 4 ? 4 - n_exist : 0;
             unsigned long long padmask = 0;
@@ -593,7 +696,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                     cnta[0] = cnt_ref; proda[0] = prod_ref;            // speculation hit: no second pass
                 } else {
                     // pass B: per existing allele, count and P(reads | allele)  (:62-77)
-                    for (int s = b0 + j; s < b1; s += G) {
+                    for (int s = b0 + jc; s < b1; s += Gc) {
                         const uint32_t st = fmin[s];
                         if (st & ST_PRESENT) {
                             const int a = KEY_ALLELE(st);
@@ -609,8 +712,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        cnta[k] = wave_reduce_add(cnta[k], G);
-                        proda[k] = wave_reduce_mul(proda[k], G);
+                        cnta[k] = wave_reduce_add(cnta[k], Gc);
+                        proda[k] = wave_reduce_mul(proda[k], Gc);
                     }
                 }
                 // PCR-error terms (:79-81); min over the other keys == value at their max count
@@ -652,7 +755,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                     predpad = x > 0.0 ? -log10(x) : 16.0;
                     if (predpad > mx) mx = predpad;
                 }
-                if (j == 0) {
+                if (jc == 0) {
                     int n_max = 0, cons = -1;
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
@@ -687,7 +790,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                 // instead of cached in registers.
                 auto scan_allele = [&](int a, int& cnt, double& prod) {
                     cnt = 0; prod = 1.0;
-                    for (int s = b0 + j; s < b1; s += G) {
+                    for (int s = b0 + jc; s < b1; s += Gc) {
                         const uint32_t st = fmin[s];
                         if (st & ST_PRESENT) {
                             const double p = prob_of(st);
@@ -696,8 +799,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                             prod *= same ? 1.0 - p : p;
                         }
                     }
-                    cnt = wave_reduce_add(cnt, G);
-                    prod = wave_reduce_mul(prod, G);
+                    cnt = wave_reduce_add(cnt, Gc);
+                    prod = wave_reduce_mul(prod, Gc);
                 };
                 int max1 = -1, max2 = -1, arg1 = -1;
                 for (unsigned long long mm = mask; mm; mm &= mm - 1) {
@@ -728,12 +831,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                     const double pred = x > 0.0 ? -log10(x) : 16.0;
                     if (pred > mx) { mx = pred; n_max = 1; cons = a; }
                     else if (pred == mx) ++n_max;
-                    if (j == 0) {
+                    if (jc == 0) {
                         const long long fx = (long long)(pred * fxscale + 0.5);
                         if (a < 4) pi_acc[a] += fx; else atomicAdd(&pifx[a], (unsigned long long)fx);
                     }
                 }
-                if (j == 0) {
+                if (jc == 0) {
                     touch_lo |= (uint32_t)mask; touch_hi |= (uint32_t)(mask >> 32);
                     if (n_max == 1) {
                         const bool str = mx > P.smt;
@@ -765,7 +868,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
             atomicOr(&H->misc[M_TOUCH_LO], touch_lo); atomicOr(&H->misc[M_TOUCH_HI], touch_hi);
         }
         __syncthreads();
-        STAMP(6);
+        STAMP(7);
         if (SMC_ABLATE == 4) return;
 
         // ---- E: ranking and candidates (:534-555), one thread
@@ -831,12 +934,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
             } else {
                 fill(R->cand[1], -1);
             }
+            // loci whose candidate(s) go through filterVariants are queued for k_filter_loci
+            if (R->cand[0].flt_applied || R->cand[1].flt_applied) flt_list[1 + atomicAdd(&flt_list[0], 1u)] = (uint32_t)li;
         }
         __syncthreads();
         const uint32_t* src = (const uint32_t*)rowst;
         uint32_t* dst = (uint32_t*)out;
         for (int i = tid; i < (int)(sizeof(smc_row) / 4); i += BLOCK) dst[i] = src[i];
-        STAMP(7);
+        STAMP(9);
+        STAMP_FLUSH();
     }
 }
 
@@ -874,13 +980,15 @@ __device__ void wave_fisher(long long a, long long b, long long c, long long d, 
     *pval = p < 1.0 ? p : 1.0;
 }
 
-__global__ __launch_bounds__(WAVE) void k_filter_loci(KParams P, const smc_locus* __restrict__ loci, smc_row* __restrict__ rows, int n_loci) {
-    const int li = blockIdx.x;
-    if (li >= n_loci) return;
-    smc_row* R = rows + li;
-    if ((R->status & 0xff) != SMC_ST_OK) return;
-    const smc_locus L = loci[li];
+__global__ __launch_bounds__(WAVE) void k_filter_loci(KParams P, const smc_locus* __restrict__ loci, smc_row* __restrict__ rows,
+                                                      const uint32_t* __restrict__ flt_list) {
+    const uint32_t n_work = flt_list[0];
     const int lane = threadIdx.x;
+    for (uint32_t w = blockIdx.x; w < n_work; w += gridDim.x) {
+    const int li = (int)flt_list[1 + w];
+    smc_row* R = rows + li;
+    if ((R->status & 0xff) != SMC_ST_OK) continue;
+    const smc_locus L = loci[li];
     for (int ci = 0; ci < 2; ++ci) {
         smc_cand* C = &R->cand[ci];
         if (C->allele < 0 || !C->flt_applied) continue;        // wave-uniform
@@ -922,6 +1030,7 @@ __global__ __launch_bounds__(WAVE) void k_filter_loci(KParams P, const smc_locus
             C->flt = f; C->vmf_lt_099 = vmf;
             C->p_sb = p_sb; C->p_r1 = p_r1; C->p_r2 = p_r2; C->p_pr = p_pr;
         }
+    }
     }
 }
 
@@ -971,6 +1080,7 @@ struct smc_plan {
     smc_ctx* ctx;
     int64_t n_loci;
     smc_locus* d_loci = nullptr;
+    uint32_t* d_flt_list = nullptr;   // [0] = count, then locus indices queued for k_filter_loci
     std::vector<Bin> bins;
     // optional HIP-event timing of the dominant k_call_loci launch (the bin with most reads)
     int timing = 0, dom_bin = -1;
@@ -988,7 +1098,7 @@ static hipError_t launch_bin(const Bin& b, const KParams& kp, const smc_plan* p,
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)b.order.size()), dim3(BLOCK), b.lds_bytes, st, kp, b.d_loci, b.d_order, b.a_cap,
-                       meta, umi, frag, dist, p->ctx->lut, rows, b.d_scratch, b.d_scratch_off);
+                       meta, umi, frag, dist, p->ctx->lut, rows, b.d_scratch, b.d_scratch_off, p->d_flt_list);
     return hipGetLastError();
 }
 
@@ -1037,6 +1147,7 @@ void smc_plan_destroy(smc_plan* p) {
     if (!p) return;
     (void)hipSetDevice(p->ctx->device);
     (void)hipFree(p->d_loci);
+    (void)hipFree(p->d_flt_list);
     for (auto e : p->ev0) (void)hipEventDestroy(e);
     for (auto e : p->ev1) (void)hipEventDestroy(e);
     for (auto& b : p->bins) {
@@ -1075,6 +1186,7 @@ int smc_plan_create(smc_ctx* ctx, const smc_locus* loci, int64_t n_loci, smc_pla
         b.order.push_back((int)l);
         if (a_cap > b.a_cap) b.a_cap = a_cap;
     }
+    HIPCHK(hipMalloc(&p->d_flt_list, sizeof(uint32_t) * ((size_t)n_loci + 4)));
     if (n_loci) {
         HIPCHK(hipMalloc(&p->d_loci, sizeof(smc_locus) * (size_t)n_loci));
         HIPCHK(hipMemcpy(p->d_loci, loci, sizeof(smc_locus) * (size_t)n_loci, hipMemcpyHostToDevice));
@@ -1165,6 +1277,7 @@ int smc_plan_run(smc_plan* p, const smc_params* prm, const uint32_t* meta, const
     HIPCHK(hipSetDevice(p->ctx->device));
     hipStream_t st = (hipStream_t)stream;
     KParams kp{prm->min_bq, prm->min_mq, prm->mt_drop, prm->primer_dist, prm->ds, prm->smt};
+    HIPCHK(hipMemsetAsync(p->d_flt_list, 0, 16, st));
     for (size_t bi = 0; bi < p->bins.size(); ++bi) {
         const Bin& b = p->bins[bi];
         const bool timed = p->timing > 0 && (int)bi == p->dom_bin;
@@ -1181,7 +1294,8 @@ int smc_plan_run(smc_plan* p, const smc_params* prm, const uint32_t* meta, const
         if (e != hipSuccess) return fail(SMC_E_HIP, std::string("k_call_loci launch: ") + hipGetErrorString(e));
         if (timed) { HIPCHK(hipEventRecord(p->ev1[slot], st)); p->n_timed++; }
     }
-    hipLaunchKernelGGL(k_filter_loci, dim3((unsigned)p->n_loci), dim3(WAVE), 0, st, kp, p->d_loci, rows, (int)p->n_loci);
+    const unsigned fgrid = (unsigned)(p->n_loci < 2048 ? p->n_loci : 2048);
+    hipLaunchKernelGGL(k_filter_loci, dim3(fgrid), dim3(WAVE), 0, st, kp, p->d_loci, rows, p->d_flt_list);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SMC_E_HIP, std::string("k_filter_loci launch: ") + hipGetErrorString(e));
     return SMC_OK;
