@@ -1,0 +1,401 @@
+"""BAM decode -> per-locus pileup records.
+
+pysam is not available where this runs, so this module reads BGZF/BAM itself (zlib) and produces,
+for every requested locus, what the reference takes from `samfile.pileup(region, truncate=True,
+max_depth=1000000, stepper='nofilter')` at smCounter.py:316-448:
+
+* every mapped alignment whose reference span covers the position, in file (coordinate) order -
+  no flag, MAPQ or base-quality filtering, duplicates / secondary / supplementary included,
+  no mate-overlap handling;
+* per alignment: `query_position` (index into the read incl. soft clips), `is_del` (position inside
+  a D or N operation), `indel` (length of the insertion (+) / deletion (-) that starts right after
+  this position, i.e. the position is the last base of an M block followed by I / D);
+* the facts of smCounter.py:319-366: UMI and read id from the qname, MAPQ, NM, CIGAR summary,
+  lengths, flags.
+
+The result is a `pileup.PileupBatch` (dense barcode / fragment ids, per-locus allele tables).
+pysam/samtools pileup semantics are not pinned by the reference (no version, BAM not shipped):
+this follows samtools 0.1.19's resolve_cigar, the era the README names.
+
+A small BAM writer (`write_bam`) is included for tests and fixtures.
+"""
+from __future__ import annotations
+
+import struct
+import zlib
+from typing import Dict, Iterable, Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .pileup import (BASE_ALLELES, F_HAS_NM, F_READ1, F_READ2, F_REVERSE, PileupBatch)
+
+_SEQ_CODE = "=ACMGRSVTWYHKDBN"
+_CIG_M, _CIG_I, _CIG_D, _CIG_N, _CIG_S, _CIG_H, _CIG_P, _CIG_EQ, _CIG_X = range(9)
+_REF_OPS = (_CIG_M, _CIG_D, _CIG_N, _CIG_EQ, _CIG_X)
+_QRY_OPS = (_CIG_M, _CIG_I, _CIG_S, _CIG_EQ, _CIG_X)
+
+
+class BamError(Exception):
+    pass
+
+
+# ------------------------------------------------------------------------------------------------
+# BGZF
+# ------------------------------------------------------------------------------------------------
+class BgzfReader(object):
+    """Sequential / seekable reader over BGZF blocks; `tell`/`seek` use BAM virtual offsets."""
+
+    def __init__(self, path: str):
+        self._fh = open(path, "rb")
+        self._block_start = 0
+        self._buf = b""
+        self._off = 0
+        self._next_block = 0
+
+    def close(self):
+        self._fh.close()
+
+    def _load_block(self, coffset: int) -> bool:
+        self._fh.seek(coffset)
+        hdr = self._fh.read(18)
+        if len(hdr) < 18:
+            self._buf, self._off = b"", 0
+            return False
+        if hdr[0] != 31 or hdr[1] != 139 or hdr[12:14] != b"BC":
+            raise BamError("not a BGZF block at offset %d" % coffset)
+        xlen = struct.unpack_from("<H", hdr, 10)[0]
+        bsize = struct.unpack_from("<H", hdr, 16)[0] + 1
+        rest = self._fh.read(bsize - 18)
+        cdata = rest[xlen - 6:-8]
+        self._buf = zlib.decompress(cdata, -15) if cdata else b""
+        self._off = 0
+        self._block_start = coffset
+        self._next_block = coffset + bsize
+        return True
+
+    def seek(self, voffset: int):
+        self._load_block(voffset >> 16)
+        self._off = voffset & 0xFFFF
+
+    def tell(self) -> int:
+        return (self._block_start << 16) | self._off
+
+    def read(self, n: int) -> bytes:
+        out = []
+        while n > 0:
+            if self._off >= len(self._buf):
+                if not self._load_block(self._next_block):
+                    break
+                continue
+            take = self._buf[self._off:self._off + n]
+            out.append(take)
+            self._off += len(take)
+            n -= len(take)
+        return b"".join(out)
+
+
+def _bgzf_block(data: bytes) -> bytes:
+    comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+    c = comp.compress(data) + comp.flush()
+    bsize = len(c) + 25
+    return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize) + c
+            + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+
+
+# ------------------------------------------------------------------------------------------------
+# BAM records
+# ------------------------------------------------------------------------------------------------
+class Alignment(object):
+    __slots__ = ("tid", "pos", "end", "qname", "flag", "mapq", "cigar", "seq", "qual", "nm", "has_nm",
+                 "l_seq")
+
+
+def _parse_aux_nm(aux: bytes):
+    i, n = 0, len(aux)
+    fixed = {ord("A"): 1, ord("c"): 1, ord("C"): 1, ord("s"): 2, ord("S"): 2, ord("i"): 4, ord("I"): 4,
+             ord("f"): 4}
+    fmt = {ord("c"): "<b", ord("C"): "<B", ord("s"): "<h", ord("S"): "<H", ord("i"): "<i", ord("I"): "<I"}
+    while i + 3 <= n:
+        tag, typ = aux[i:i + 2], aux[i + 2]
+        i += 3
+        if typ in fixed:
+            if tag == b"NM" and typ in fmt:
+                return struct.unpack_from(fmt[typ], aux, i)[0], True
+            i += fixed[typ]
+        elif typ in (ord("Z"), ord("H")):
+            i = aux.index(b"\x00", i) + 1
+        elif typ == ord("B"):
+            sub = aux[i]
+            cnt = struct.unpack_from("<I", aux, i + 1)[0]
+            i += 5 + cnt * fixed[sub]
+        else:
+            raise BamError("unknown aux type %r" % chr(typ))
+    return 0, False            # the reference's default when no NM tag is present (smCounter.py:329)
+
+
+def _parse_record(b: bytes) -> Alignment:
+    tid, pos, l_name, mapq, _bin, n_cig, flag, l_seq, _ntid, _npos, _tlen = struct.unpack_from("<iiBBHHHiiii", b, 0)
+    a = Alignment()
+    a.tid, a.pos, a.mapq, a.flag, a.l_seq = tid, pos, mapq, flag, l_seq
+    o = 32
+    a.qname = b[o:o + l_name - 1].decode()
+    o += l_name
+    cig = struct.unpack_from("<%dI" % n_cig, b, o) if n_cig else ()
+    a.cigar = [(c & 15, c >> 4) for c in cig]
+    o += 4 * n_cig
+    nb = (l_seq + 1) // 2
+    packed = b[o:o + nb]
+    o += nb
+    s = []
+    for byte in packed:
+        s.append(_SEQ_CODE[byte >> 4])
+        s.append(_SEQ_CODE[byte & 15])
+    a.seq = "".join(s[:l_seq])
+    a.qual = b[o:o + l_seq]
+    o += l_seq
+    a.nm, a.has_nm = _parse_aux_nm(b[o:])
+    a.end = pos + sum(l for op, l in a.cigar if op in _REF_OPS)
+    return a
+
+
+class BamFile(object):
+    def __init__(self, path: str):
+        self.path = path
+        self._bg = BgzfReader(path)
+        if self._bg.read(4) != b"BAM\x01":
+            raise BamError("%s is not a BAM file" % path)
+        l_text = struct.unpack("<i", self._bg.read(4))[0]
+        self.header_text = self._bg.read(l_text).decode(errors="replace")
+        n_ref = struct.unpack("<i", self._bg.read(4))[0]
+        self.refs: List[Tuple[str, int]] = []
+        for _ in range(n_ref):
+            l_name = struct.unpack("<i", self._bg.read(4))[0]
+            name = self._bg.read(l_name)[:-1].decode()
+            self.refs.append((name, struct.unpack("<i", self._bg.read(4))[0]))
+        self.tid_of = {n: i for i, (n, _) in enumerate(self.refs)}
+        self._first_record = self._bg.tell()
+        self._lin_index = _load_bai(path + ".bai", n_ref) or _load_bai(path[:-4] + ".bai", n_ref)
+
+    def close(self):
+        self._bg.close()
+
+    def _records(self) -> Iterator[Alignment]:
+        while True:
+            h = self._bg.read(4)
+            if len(h) < 4:
+                return
+            yield _parse_record(self._bg.read(struct.unpack("<i", h)[0]))
+
+    def fetch(self, chrom: str, start: int, end: int) -> List[Alignment]:
+        """Mapped alignments overlapping [start, end) (0-based), in file order.  Uses the BAI linear
+        index when present, else scans from the first record (file must be coordinate-sorted)."""
+        tid = self.tid_of.get(chrom)
+        if tid is None:
+            return []
+        voff = self._first_record
+        if self._lin_index and tid < len(self._lin_index) and self._lin_index[tid]:
+            iv = self._lin_index[tid]
+            w = min(start >> 14, len(iv) - 1)
+            while w >= 0 and iv[w] == 0:
+                w -= 1
+            if w >= 0:
+                voff = iv[w]
+        self._bg.seek(voff)
+        out = []
+        for a in self._records():
+            if a.tid < 0 or a.tid > tid or (a.tid == tid and a.pos >= end):
+                break
+            if a.tid < tid or (a.flag & 0x4) or not a.cigar:
+                continue
+            if a.end > start:
+                out.append(a)
+        return out
+
+
+def _load_bai(path: str, n_ref: int):
+    try:
+        b = open(path, "rb").read()
+    except OSError:
+        return None
+    if b[:4] != b"BAI\x01":
+        return None
+    o = 8
+    lin = []
+    for _ in range(struct.unpack_from("<i", b, 4)[0]):
+        n_bin = struct.unpack_from("<i", b, o)[0]
+        o += 4
+        for _ in range(n_bin):
+            n_chunk = struct.unpack_from("<i", b, o + 4)[0]
+            o += 8 + 16 * n_chunk
+        n_intv = struct.unpack_from("<i", b, o)[0]
+        o += 4
+        lin.append(list(struct.unpack_from("<%dQ" % n_intv, b, o)))
+        o += 8 * n_intv
+    return lin
+
+
+def write_bam(path: str, refs: Sequence[Tuple[str, int]], records: Iterable[dict], block: int = 60000) -> None:
+    """Tiny BAM writer (coordinate-sorted input expected).  record keys: tid, pos, qname, flag, mapq,
+    cigar [(op, len)], seq, qual (bytes or list of ints), nm (int or None)."""
+    text = "@HD\tVN:1.4\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in refs)
+    out = [b"BAM\x01", struct.pack("<i", len(text)), text.encode(), struct.pack("<i", len(refs))]
+    for name, ln in refs:
+        out.append(struct.pack("<i", len(name) + 1) + name.encode() + b"\x00" + struct.pack("<i", ln))
+    for r in records:
+        seq = r["seq"]
+        qual = bytes(r["qual"])
+        packed = bytearray((len(seq) + 1) // 2)
+        for i, ch in enumerate(seq):
+            packed[i >> 1] |= _SEQ_CODE.index(ch) << (4 if i % 2 == 0 else 0)
+        cig = b"".join(struct.pack("<I", (l << 4) | op) for op, l in r["cigar"])
+        aux = b"" if r.get("nm") is None else b"NMC" + struct.pack("<B", r["nm"])
+        name = r["qname"].encode() + b"\x00"
+        body = struct.pack("<iiBBHHHiiii", r["tid"], r["pos"], len(name), r["mapq"], 4680, len(r["cigar"]),
+                           r["flag"], len(seq), -1, -1, 0) + name + cig + bytes(packed) + qual + aux
+        out.append(struct.pack("<i", len(body)) + body)
+    data = b"".join(out)
+    with open(path, "wb") as fh:
+        for i in range(0, len(data), block):
+            fh.write(_bgzf_block(data[i:i + block]))
+        fh.write(_bgzf_block(b""))
+
+
+# ------------------------------------------------------------------------------------------------
+# pileup
+# ------------------------------------------------------------------------------------------------
+def _column(a: Alignment, pos0: int):
+    """(qpos, is_del, indel) of alignment `a` at 0-based reference position pos0, or None."""
+    x, y = a.pos, 0
+    cig = a.cigar
+    for k, (op, l) in enumerate(cig):
+        if op in (_CIG_M, _CIG_EQ, _CIG_X):
+            if x <= pos0 < x + l:
+                indel = 0
+                if pos0 == x + l - 1 and k + 1 < len(cig):
+                    nop, nl = cig[k + 1]
+                    if nop == _CIG_I:
+                        indel = nl
+                    elif nop == _CIG_D:
+                        indel = -nl
+                return y + (pos0 - x), False, indel
+            x += l
+            y += l
+        elif op in (_CIG_I, _CIG_S):
+            y += l
+        elif op in (_CIG_D, _CIG_N):
+            if x <= pos0 < x + l:
+                return y, True, 0
+            x += l
+    return None
+
+
+class _LocusBuilder(object):
+    def __init__(self):
+        self.cols = {k: [] for k in ("umi", "frag", "flag", "mq", "nm", "n_indel", "left_sp", "qlen", "qalen",
+                                     "qpos", "indel", "is_del", "allele", "bq")}
+        self.chrom, self.pos, self.ref, self.alleles, self.off = [], [], [], [], [0]
+
+    def add_locus(self, chrom: str, pos1: int, reads: List[Alignment], fasta):
+        pos0 = pos1 - 1
+        table = list(BASE_ALLELES)
+        index = {s: i for i, s in enumerate(table)}
+        umis: Dict[str, int] = {}
+        frags: List[Dict[str, int]] = []
+        c = self.cols
+        n = 0
+        for a in reads:
+            col = _column(a, pos0)
+            if col is None:
+                continue
+            qpos, is_del, indel = col
+            parts = a.qname.split(":")
+            if len(parts) < 3:
+                raise BamError("read name %r has fewer than 3 ':' fields; the reference needs "
+                               "<readid>:<tag>:<UMI>:<x> (smCounter.py:320-325)" % a.qname)
+            bc, readid = parts[-2], ":".join(parts[:-2])
+            u = umis.setdefault(bc, len(umis))
+            if u == len(frags):
+                frags.append({})
+            f = frags[u].setdefault(readid, len(frags[u]))
+            if a.l_seq == 0:
+                raise BamError("alignment %s has no sequence; the reference indexes query_sequence" % a.qname)
+            if is_del:
+                key, bq = "DEL", 0
+            else:
+                site = a.seq[qpos]
+                bq = a.qual[qpos]
+                if indel > 0:
+                    key = "INS|" + site + "|" + site + a.seq[qpos + 1:qpos + 1 + indel]
+                elif indel < 0:
+                    key = "DEL|" + site + fasta.fetch(chrom, pos1, pos1 - indel).upper() + "|" + site
+                else:
+                    key = site
+            ai = index.get(key)
+            if ai is None:
+                ai = index[key] = len(table)
+                table.append(key)
+            cig = a.cigar
+            c["umi"].append(u)
+            c["frag"].append(f)
+            c["flag"].append((F_READ1 if a.flag & 0x40 else 0) | (F_READ2 if a.flag & 0x80 else 0)
+                             | (F_REVERSE if a.flag & 0x10 else 0) | (F_HAS_NM if a.has_nm else 0))
+            c["mq"].append(a.mapq)
+            c["nm"].append(a.nm)
+            c["n_indel"].append(sum(l for op, l in cig if op in (_CIG_I, _CIG_D)))
+            c["left_sp"].append(cig[0][1] if cig[0][0] == _CIG_S else 0)
+            c["qlen"].append(a.l_seq)
+            c["qalen"].append(sum(l for op, l in cig if op in (_CIG_M, _CIG_I, _CIG_EQ, _CIG_X)))
+            c["qpos"].append(qpos)
+            c["indel"].append(indel)
+            c["is_del"].append(is_del)
+            c["allele"].append(ai)
+            c["bq"].append(bq)
+            n += 1
+        self.chrom.append(chrom)
+        self.pos.append(pos1)
+        self.ref.append(fasta.fetch(chrom, pos0, pos1).upper())
+        self.alleles.append(table)
+        self.off.append(self.off[-1] + n)
+
+    def build(self) -> PileupBatch:
+        dt = dict(umi=np.uint32, frag=np.uint32, flag=np.uint8, mq=np.uint8, nm=np.uint32, n_indel=np.uint32,
+                  left_sp=np.uint32, qlen=np.uint32, qalen=np.uint32, qpos=np.int32, indel=np.int32,
+                  is_del=bool, allele=np.uint8, bq=np.uint8)
+        return PileupBatch(chrom=self.chrom, pos=np.array(self.pos, np.int64), ref=self.ref,
+                           alleles=self.alleles, read_off=np.array(self.off, np.int64),
+                           **{k: np.array(v, dt[k]) for k, v in self.cols.items()})
+
+
+def iter_pileup_batches(bam: BamFile, fasta, loci: Sequence[Tuple[str, str]], max_reads: int = 2_000_000):
+    """Yield (first locus index, PileupBatch) chunks covering `loci` [(chrom, '1-based pos')] in order;
+    a chunk closes once it holds max_reads pileup reads.  Consecutive positions of one chromosome
+    share one fetch."""
+    i, n = 0, len(loci)
+    while i < n:
+        builder = _LocusBuilder()
+        first = i
+        while i < n and builder.off[-1] < max_reads:
+            chrom = loci[i][0]
+            j = i
+            while j + 1 < n and loci[j + 1][0] == chrom and int(loci[j + 1][1]) == int(loci[j][1]) + 1 \
+                    and j + 1 - i < 4096:
+                j += 1
+            lo, hi = int(loci[i][1]) - 1, int(loci[j][1])          # 0-based [lo, hi)
+            reads = bam.fetch(chrom, lo, hi)
+            w0 = 0
+            for k in range(i, j + 1):
+                p0 = int(loci[k][1]) - 1
+                while w0 < len(reads) and reads[w0].end <= p0:
+                    w0 += 1            # sorted by start: a head read that ended is never needed again
+                cover = []
+                for r in reads[w0:]:
+                    if r.pos > p0:
+                        break
+                    if p0 < r.end:
+                        cover.append(r)
+                builder.add_locus(chrom, p0 + 1, cover, fasta)
+                if builder.off[-1] >= max_reads:
+                    j = k
+                    break
+            i = j + 1
+        yield first, builder.build()

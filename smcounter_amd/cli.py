@@ -1,0 +1,110 @@
+"""Command line of the MI355X build: the reference's flags, inputs and output files
+(smCounter.py:616-640 argParseInit, :645-909 main), with the per-locus worker pool replaced by batched
+launches on one GPU.
+
+    python -m smcounter_amd.cli --outPrefix example --bamFile example.bam --bedTarget example.bed \\
+        --mtDepth 3612 --rpb 8.6 --refGenome hg19.fasta [...]
+
+Differences that do not change results: `--nCPU` is accepted and ignored (the pool is gone);
+`--bedtoolsPath` is accepted and ignored (merge/sort/intersect run in-process, bedops.py); when the two
+repeat BEDs are absent the repeat flags are skipped with a note instead of failing inside bedtools.
+"""
+from __future__ import annotations
+
+import argparse
+import datetime
+import os
+import sys
+
+from . import bamio, bedops, fasta, postfilter, runlog, vc, writers
+from .params import VcParams
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description="Variant calling using molecular barcodes (MI355X build)",
+                                fromfile_prefix_chars="@")
+    p.add_argument("--outPrefix", default=None, required=True, help="prefix for output files")
+    p.add_argument("--bamFile", default=None, required=True, help="BAM file")
+    p.add_argument("--bedTarget", default=None, required=True, help="BED file for target region")
+    p.add_argument("--mtDepth", default=None, required=True, type=int, help="Mean MT depth")
+    p.add_argument("--rpb", default=None, required=True, type=float, help="Mean read pairs per MT")
+    p.add_argument("--nCPU", type=int, default=1, help="ignored: loci are batched onto the GPU")
+    p.add_argument("--minBQ", type=int, default=20, help="minimum base quality allowed for analysis")
+    p.add_argument("--minMQ", type=int, default=30, help="minimum mapping quality allowed for analysis")
+    p.add_argument("--hpLen", type=int, default=10, help="Minimum length for homopolymers")
+    p.add_argument("--mismatchThr", type=float, default=6.0, help="average number of mismatches per 100 bases allowed")
+    p.add_argument("--mtDrop", type=int, default=0, help="Drop MTs with lower than or equal to X reads.")
+    p.add_argument("--maxMT", type=int, default=0, help="Randomly downsample to X MTs; 0 = 2.0 * mean MT depth")
+    p.add_argument("--primerDist", type=int, default=2, help="filter variants that are within X bases to primer")
+    p.add_argument("--threshold", type=int, default=0, help="Minimum prediction index for a variant to be called; "
+                                                             "0 = chosen from the mean MT depth")
+    p.add_argument("--refGenome", default=None, required=False, help="indexed FASTA of the reference genome")
+    p.add_argument("--bedTandemRepeats", default=None, help="bed for UCSC tandem repeats")
+    p.add_argument("--bedRepeatMaskerSubset", default=None, help="bed for RepeatMasker simple repeats, low complexity, "
+                                                                  "microsatellite regions")
+    p.add_argument("--bedtoolsPath", default=None, help="ignored: BED operations run in-process")
+    p.add_argument("--runPath", default=None, help="path to working directory")
+    p.add_argument("--logFile", default=None, help="log file")
+    p.add_argument("--paramFile", default=None, help="optional parameter file; if given it replaces every other "
+                                                     "parameter except --logFile")
+    p.add_argument("--device", type=int, default=0, help="GPU index")
+    p.add_argument("--batchReads", type=int, default=4_000_000, help="pileup reads per device batch")
+    return p
+
+
+def main(args) -> int:
+    """Same contract as the reference's main(args): accepts a Namespace or a dict of argument values,
+    returns the PI threshold used (smCounter.py:909)."""
+    t0 = datetime.datetime.now()
+    print("smCounter started at " + str(t0))
+    parser = build_parser()
+    if not isinstance(args, argparse.Namespace):
+        args = parser.parse_args(["--{0}={1}".format(k, v) for k, v in args.items()])
+    elif args.paramFile is not None:
+        args = parser.parse_args(("@" + args.paramFile,))
+    for k, v in vars(args).items():
+        print((k, v))
+    if args.runPath is not None:
+        os.chdir(args.runPath)
+    if not args.refGenome:
+        raise SystemExit("--refGenome is required (indexed FASTA)")
+
+    params = VcParams(minBQ=args.minBQ, minMQ=args.minMQ, mtDepth=args.mtDepth, rpb=args.rpb, hpLen=args.hpLen,
+                      mismatchThr=args.mismatchThr, mtDrop=args.mtDrop, maxMT=args.maxMT, primerDist=args.primerDist)
+    loc_list = bedops.expand_loci(args.bedTarget)
+    ref = fasta.FastaFile(args.refGenome)
+    bam = bamio.BamFile(args.bamFile)
+    from .engine import Engine
+    eng = Engine(args.device)
+    output = []
+    for first, pb in bamio.iter_pileup_batches(bam, ref, loc_list, max_reads=args.batchReads):
+        output.extend(vc.vc_batch(pb, params, ref, eng=eng))
+    eng.close()
+    bam.close()
+    vc.raise_on_exception(output, loc_list)
+
+    print("begin variant filtering and output")
+    have_rep = [b for b in (args.bedTandemRepeats, args.bedRepeatMaskerSubset) if b and os.path.exists(b)]
+    if len(have_rep) < 2:
+        print("note: repeat tracks not given or not found; RepT/RepS/LowC/SL flags are not applied")
+    trf, rm = postfilter.load_repeat_regions(
+        args.bedTarget,
+        args.bedTandemRepeats if args.bedTandemRepeats and os.path.exists(args.bedTandemRepeats) else None,
+        args.bedRepeatMaskerSubset if args.bedRepeatMaskerSubset and os.path.exists(args.bedRepeatMaskerSubset) else None)
+    output = postfilter.apply_repeat_filters(output, trf, rm)
+    threshold = writers.pi_threshold(args.mtDepth, args.threshold)
+    writers.write_outputs(args.outPrefix, output, threshold)
+    t1 = datetime.datetime.now()
+    print("smCounter completed running at " + str(t1))
+    print("smCounter total time: " + str(t1 - t0))
+    return threshold
+
+
+if __name__ == "__main__":
+    ns = build_parser().parse_args()
+    if ns.logFile:
+        runlog.init(ns.logFile)
+    try:
+        main(ns)
+    finally:
+        runlog.close()

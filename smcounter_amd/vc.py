@@ -1,0 +1,47 @@
+"""Batch equivalent of the reference's per-locus worker call.
+
+`vc_batch` plays the role of `[pool.apply_async(vc_wrapper, ...) for x in locList]` +
+`[p.get() for p in results]` (smCounter.py:683-685): one string per locus, in submission order,
+each either the 45-field row of `vc()` (:599), the Zero_Coverage row (:493), or - for a locus the
+device flagged - the reference's failure convention `"Exception thrown!\\n" + traceback`
+(:605-611), which the caller detects by prefix and re-raises (:689-694, `raise_on_exception`)."""
+from __future__ import annotations
+
+import traceback
+from typing import List, Optional
+
+from . import abi, engine as _engine, features, rows
+from .params import VcParams
+from .pileup import PileupBatch
+
+EXC_PREFIX = "Exception thrown!"
+
+
+def vc_batch(pb: PileupBatch, params: VcParams, refprov, eng: Optional[_engine.Engine] = None,
+             device: int = 0) -> List[str]:
+    own = eng is None
+    if own:
+        eng = _engine.Engine(device)           # raises loudly without a GPU: there is no CPU path
+    try:
+        db = features.extract_features(pb, params)
+        out_rows = eng.call_batch_host(db, params)
+    finally:
+        if own:
+            eng.close()
+    text = []
+    for l in range(db.n_loci):
+        try:
+            text.append(rows.format_row(out_rows[l], db.chrom[l], db.pos[l], db.ref[l], db.alleles[l],
+                                        params, refprov))
+        except Exception:
+            print("Exception thrown in vc() function at genome location:", db.chrom[l], int(db.pos[l]))
+            text.append(EXC_PREFIX + "\n" + traceback.format_exc())
+    return text
+
+
+def raise_on_exception(output: List[str], loc_list) -> None:
+    """main()'s scan for worker failures (smCounter.py:689-694)."""
+    for line, loc in zip(output, loc_list):
+        if line.startswith(EXC_PREFIX):
+            print(line)
+            raise Exception("Exception thrown in vc() at location: " + str(loc))
