@@ -23,17 +23,14 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-from smcounter_amd import abi, engine, synth  # noqa: E402
-from smcounter_amd import dist as smcdist  # noqa: E402
-
+# heavy imports happen inside main(): the CPU leg's spawned workers re-import this module
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
 def main():
+    global np, torch, dist, abi, engine, synth, smcdist
+    import numpy as np
+    from smcounter_amd import abi, synth
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -50,6 +47,14 @@ def main():
     if world != a.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)"
                          % (a.gpus, world))
+    # The CPU leg runs FIRST, before this process touches the GPU: it starts worker processes.
+    cpu = None
+    if world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_leg(a)
+    import torch
+    import torch.distributed as dist
+    from smcounter_amd import engine
+    from smcounter_amd import dist as smcdist
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -78,7 +83,7 @@ def main():
         loc["read_off"] += off
         loci_parts.append(loc)
         if sample is None:
-            sample = db                                           # kept for the CPU leg / parity check
+            sample = db
     loci = np.concatenate(loci_parts)
     plan = eng.make_plan(loci)
     rows = plan.alloc_rows()
@@ -139,29 +144,47 @@ def main():
                          "kernel_ms": k_ms, "kernel_samples": k_n, "loci_per_launch": k_loci,
                          "alg_bytes_per_launch": alg_bytes},
         }
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"], out["parity_sample"] = cpu_leg(sample, params, plan, rows)
+        if cpu is not None:
+            out["cpu_baseline"], out["cpu_baseline_c"] = cpu["python_pool"], cpu["c_port"]
+            gpu_rows = plan.download(rows)[:len(cpu["rows"])]
+            bad = abi.compare_rows(gpu_rows, cpu["rows"], fragile=cpu["fragile"])
+            out["parity_sample"] = {"loci": len(gpu_rows), "mismatches": len(bad), "detail": bad[:3]}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_leg(sample, params, plan, rows):
-    """The C restatement (oracle/) on one host core over the first chunk of the same workload, and a
-    field-by-field check of the GPU rows of that chunk against it."""
+def cpu_leg(a):
+    """CPU baselines on a bounded sample of the same workload (first chunk of the config):
+    * python_pool - oracle/vc_port.py, the pure-Python restatement of vc(), driven like the reference's
+      main(): multiprocessing.Pool(all host cores), one task per locus, on the first 2000 loci;
+    * c_port - oracle/smc_oracle.c on one core over the whole first chunk; its rows are kept to check
+      the GPU rows of that chunk field by field after the timed run."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_lib
+    import vc_port
+    cfg = synth.CONFIGS[a.config]
+    params = synth.params_for(cfg)
+    n_loc = a.loci_per_gpu or cfg.n_loci
+    sample = synth.generate_native(cfg, 0, min(a.chunk, n_loc), params)
     n = sample.n_loci
     t = time.perf_counter()
-    ref_rows = oracle_lib.call_batch(sample, abi.c_params(params), abi.ROW_DTYPE)
-    dt = time.perf_counter() - t
-    gpu_rows = plan.download(rows)[:n]
-    bad = abi.compare_rows(gpu_rows, ref_rows)
-    base = {"value": n / dt, "unit": "loci/s", "cores": 1, "kind": "port",
-            "sample": "first %d loci of the same workload, C restatement oracle/smc_oracle.c, 1 thread, %.1f s"
-                      % (n, dt)}
-    return base, {"loci": n, "mismatches": len(bad), "detail": bad[:3]}
+    ref_rows, fragile = oracle_lib.call_batch(sample, abi.c_params(params), abi.ROW_DTYPE, return_fragile=True)
+    dt_c = time.perf_counter() - t
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n_py = min(n, 2000)
+    t = time.perf_counter()
+    vc_port.call_batch(sample, params, n_cpu=cores, loci=range(n_py))
+    dt_py = time.perf_counter() - t
+    return {
+        "python_pool": {"value": n_py / dt_py, "unit": "loci/s", "cores": cores, "kind": "port",
+                        "sample": "first %d loci of the same workload, pure-Python port oracle/vc_port.py under "
+                                  "multiprocessing.Pool(%d), one task per locus, %.1f s incl. pool start-up"
+                                  % (n_py, cores, dt_py)},
+        "c_port": {"value": n / dt_c, "unit": "loci/s", "cores": 1, "kind": "port",
+                   "sample": "first %d loci, C restatement oracle/smc_oracle.c, 1 thread, %.1f s" % (n, dt_c)},
+        "rows": ref_rows, "fragile": fragile}
 
 
 if __name__ == "__main__":
