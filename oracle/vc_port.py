@@ -210,7 +210,18 @@ def _task(args):
     return vc_locus(*args)
 
 
-def call_batch(db, params, n_cpu=1, loci=None):
+def _noop(x):
+    return x
+
+
+def make_pool(n_cpu):
+    """A started, warmed worker pool ("spawn": fresh interpreters, never a fork of a GPU process)."""
+    pool = multiprocessing.get_context("spawn").Pool(processes=n_cpu)
+    pool.map(_noop, range(4 * n_cpu))
+    return pool
+
+
+def call_batch(db, params, n_cpu=1, loci=None, pool=None):
     """Run the port over loci of a DeviceBatch with a process pool, one task per locus (the reference's
     dispatch, smCounter.py:683-685).  -> list of row dicts in locus order."""
     idx = range(db.n_loci) if loci is None else loci
@@ -221,9 +232,15 @@ def call_batch(db, params, n_cpu=1, loci=None):
         tasks.append((db.meta[o:o + n], db.umi[o:o + n], db.frag[o:o + n], db.dist[o:o + n], int(L["ref_allele"]),
                       int(L["n_alleles"]), int(L["snp_mask"]), params.minBQ, params.minMQ, params.mtDrop,
                       params.primerDist, params.ds, params.smt))
-    if n_cpu <= 1:
+    if n_cpu <= 1 and pool is None:
         return [vc_locus(*t) for t in tasks]
-    # "spawn": workers are fresh interpreters (never fork a process that may hold a GPU context)
-    with multiprocessing.get_context("spawn").Pool(processes=n_cpu) as pool:
+    own = pool is None
+    if own:
+        pool = make_pool(n_cpu)
+    try:
         results = [pool.apply_async(_task, (t,)) for t in tasks]
         return [r.get() for r in results]
+    finally:
+        if own:
+            pool.close()
+            pool.join()
