@@ -312,7 +312,19 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                 ADDM(accv[SMC_T_R2BCLE], m_ref & m_r2i & m_le20);
                 ADDM(accv[SMC_T_R2PRLE], m_ref & m_r2i & m_prle);
                 lmask nr = m_ok & ~m_ref;
-                if (nr) {                                               // wave-uniform, rare
+                if (nr && __popcll(nr) <= 6) {
+                    // a few stray reads (sequencing errors): one predicated LDS add per tally, no loop
+                    uint32_t* t = tal + a * SMC_NT;
+                    if (LANES(nr)) atomicAdd(&t[SMC_T_CNT], 1u);
+                    if (LANES(nr & e_fwd)) atomicAdd(&t[SMC_T_FWD], 1u);
+                    if (LANES(nr & e_rev)) atomicAdd(&t[SMC_T_REV], 1u);
+                    if (LANES(nr & e_lowq)) atomicAdd(&t[SMC_T_LOWQ], 1u);
+                    if (LANES(nr & m_r1i)) atomicAdd(&t[SMC_T_R1N], 1u);
+                    if (LANES(nr & m_r1i & m_le20)) atomicAdd(&t[SMC_T_R1LE], 1u);
+                    if (LANES(nr & m_r2i)) atomicAdd(&t[SMC_T_R2N], 1u);
+                    if (LANES(nr & m_r2i & m_le20)) atomicAdd(&t[SMC_T_R2BCLE], 1u);
+                    if (LANES(nr & m_r2i & m_prle)) atomicAdd(&t[SMC_T_R2PRLE], 1u);
+                } else if (nr) {                                        // many: aggregate per allele
                     while (nr) {
                         const int src = __ffsll((long long)nr) - 1;
                         const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)a, src);
@@ -664,9 +676,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         STAMP(6);
 
         // ---- phase 1: the queued barcodes (more than one allele, or not the reference), general path
-        // (16 lanes per barcode here: few barcodes, so the walks shrink to one or two steps)
+        // (8 lanes per barcode here: few barcodes, short walks, and idle waves skip the phase)
         const int n_complex = (int)H->misc[M_NCOMPLEX];
-        Gc = BLOCK < 16 ? BLOCK : 16;
+        Gc = 8;
         jc = tid % Gc;
         const int grp1 = tid / Gc, ngrp1 = BLOCK / Gc;
         for (int w = grp1; w < n_complex; w += ngrp1) {
@@ -717,23 +729,29 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                     }
                 }
                 // PCR-error terms (:79-81); min over the other keys == value at their max count
-                int max1 = -1, max2 = -1, arg1 = -1;
+                int max1 = -1, max2 = -1, arg1 = -1, arg2 = -1;
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (k < n_exist) {
-                        if (cnta[k] > max1) { max2 = max1; max1 = cnta[k]; arg1 = k; }
-                        else if (cnta[k] > max2) max2 = cnta[k];
+                        if (cnta[k] > max1) { max2 = max1; arg2 = arg1; max1 = cnta[k]; arg1 = k; }
+                        else if (cnta[k] > max2) { max2 = cnta[k]; arg2 = k; }
                     }
-                double prodpcr = 1.0, tmpv[4] = {0, 0, 0, 0}, sumP = 0.0;
+                double prodpcr = 1.0, tmpv[4] = {0, 0, 0, 0}, pcrv[4] = {0, 0, 0, 0}, sumP = 0.0;
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (k < n_exist) prodpcr *= pcr_of(cnta[k], denom);
+                    if (k < n_exist) { pcrv[k] = pcr_of(cnta[k], denom); prodpcr *= pcrv[k]; }
+                // the "other keys" term needs the PCR value at the largest count among the other keys:
+                // that is one of the values just computed (equal counts give bit-equal values), or the
+                // zero-count value when the only other keys are padded ones
+                const double pcr0 = n_exist == 1 ? pcr_of(0, denom) : 0.0;
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (k < n_exist) {
-                        int other = (k == arg1) ? max2 : max1;
-                        if (other < 0) other = 0;                      // only padded keys besides this one
-                        tmpv[k] = pne * proda[k] + rightP * pcr_of(other, denom);   // :86
+                        const int oi = (k == arg1) ? arg2 : arg1;
+                        double po = pcr0;
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) po = (m == oi) ? pcrv[m] : po;
+                        tmpv[k] = pne * proda[k] + rightP * po;                       // :86
                         sumP += tmpv[k];
                     }
                 const double padOut = rightP * prodpcr;                // :88-91
@@ -751,8 +769,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                 double predpad = 0.0;
                 if (npad) {
                     const double post = sumP <= 0 ? 0.0 : padOut / sumP;
-                    const double x = 1.0 - post;
-                    predpad = x > 0.0 ? -log10(x) : 16.0;
+                    if (post < 1e-6) predpad = post * (1.0 + post * (0.5 + post * (1.0 / 3.0))) * 0.43429448190325182765;
+                    else { const double x = 1.0 - post; predpad = x > 0.0 ? -log10(x) : 16.0; }
                     if (predpad > mx) mx = predpad;
                 }
                 if (jc == 0) {
