@@ -79,7 +79,8 @@ typedef struct smc_params {
  * read_off is a multiple of 4. umi ids are < n_umi (dense, order of first appearance). frag ids are
  * locus-level fragment slots < n_frag, grouped by barcode: the fragments of barcode u occupy one
  * contiguous slot range, ranges ordered by u, each fragment's slot fixed by its first appearance
- * within the barcode; n_frag = number of distinct fragments (= allFrag, smCounter.py:483). */
+ * within the barcode; n_frag = number of distinct fragments (= allFrag, smCounter.py:483).
+ * Base qualities are Phred values <= 126 (BAM holds 0..93); larger bytes are clamped to 126. */
 typedef struct smc_locus {
     int64_t read_off;
     int32_t n_reads;

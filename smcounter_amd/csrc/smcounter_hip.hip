@@ -349,7 +349,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                     if (umi_base[u] > f) atomicMin(&umi_base[u], f);     // converges after a few reads
                     if (LANES(m_inc)) {
                         if (!umi_flag[u]) umi_flag[u] = 1;
-                        const uint32_t bq_eff = LANES(m_gap) ? (uint32_t)P.min_bq : ((mw >> 8) & 0xffu);   // :418
+                        uint32_t bq_eff = LANES(m_gap) ? (uint32_t)P.min_bq : ((mw >> 8) & 0xffu);         // :418
+                        bq_eff = bq_eff < PIDX_UNPAIRED ? bq_eff : PIDX_UNPAIRED - 1u;   // contract: quality <= 126
                         const uint32_t key = ((uint32_t)i << 14) | (a << 8) | bq_eff;
                         atomicMin(&fmin[f], key);
                         atomicMax(&fmax[f], key);
@@ -556,12 +557,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         uint32_t touch_lo = 0, touch_hi = 0;
         const double pne = 1.0 - 3e-5;                                 // pcr_no_error, :20
         const int refa = L.ref_allele;
-        auto prob_of = [&](uint32_t st) -> double {                    // :65-68
-            const uint32_t q = st & 255u;
-            double p = lut[q & (LUT_N - 1)];
-            if (q >= PIDX_UNPAIRED && (st & ST_PAIRED)) p = g_lut[q];   // never taken on real data
-            return p;
-        };
+        // error probability of a fragment: one LDS read, no branch.  The state's low byte is the merged
+        // quality (<= 126 by the batch contract, features.py) or PIDX_UNPAIRED (-> 0.1, :65-68).
+        auto prob_of = [&](uint32_t st) -> double { return lut[st & (LUT_N - 1)]; };
 
         // pass A of one barcode: fragment count, allele set, P(no sequencing error); speculatively also
         // the count and product for the locus's reference allele (the only allele of most barcodes)

@@ -40,6 +40,7 @@ FL_R2, FL_REV, FL_MMOK = 1, 2, 4
 KIND_SHIFT = 3
 KIND_BASE, KIND_INDEL_GAP, KIND_INS, KIND_DELSTART = 0, 1, 2, 3
 READ_ALIGN = 4
+MAX_BQ = 126          # device contract (smcounter_hip.hip: PIDX_UNPAIRED - 1)
 
 
 class PileupError(Exception):
@@ -128,6 +129,9 @@ def extract_features(pb: PileupBatch, params: VcParams) -> DeviceBatch:
     d_bc = np.where(regular, np.clip(d_bc, 0, 65535), 0).astype(np.uint32)
     d_pr = np.where(regular, np.clip(d_pr, 0, 65535), 0).astype(np.uint32)
 
+    if n and int(pb.bq.max()) > MAX_BQ:
+        raise PileupError("base quality %d > %d: not a Phred value a BAM can hold (0..93); the device's "
+                          "error-probability table stops at %d" % (int(pb.bq.max()), MAX_BQ, MAX_BQ))
     flags = (is_r2.astype(np.uint32) * FL_R2 | rev.astype(np.uint32) * FL_REV
              | mm_ok.astype(np.uint32) * FL_MMOK | kind << KIND_SHIFT)
     bq = pb.bq.astype(np.uint32)
