@@ -71,6 +71,7 @@ def main():
     t0 = time.time()
     stride = (cfg.depth + 3) // 4 * 4
     planes = [torch.empty(n_loc * stride, dtype=torch.int32, device=dev) for _ in range(4)]
+    planes.append(torch.empty(n_loc * (cfg.n_umi + 1), dtype=torch.int32, device=dev))      # umi_start
     loci_parts, sample = [], None
     nthreads = max(1, (os.cpu_count() or 1) // max(1, world))
     for c0 in range(lo, hi, a.chunk):
@@ -79,8 +80,11 @@ def main():
         off = (c0 - lo) * stride
         for pl, src in zip(planes, (db.meta, db.umi, db.frag, db.dist)):
             pl[off:off + db.n_slots].copy_(torch.from_numpy(src.view(np.int32)))
+        uoff = (c0 - lo) * (cfg.n_umi + 1)
+        planes[4][uoff:uoff + len(db.umi_start)].copy_(torch.from_numpy(db.umi_start.view(np.int32)))
         loc = db.loci.copy()
-        loc["read_off"] += off
+        loc["read_off4"] += off // 4
+        loc["umi_off"] += uoff
         loci_parts.append(loc)
         if sample is None:
             sample = db

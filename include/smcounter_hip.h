@@ -75,14 +75,21 @@ typedef struct smc_params {
     double smt;          /* strong-MT threshold 2.0 / 3.0 / 4.0 by rpb    smCounter.py:302-308 */
 } smc_params;
 
-/* One per locus, 32 bytes. Reads of locus l occupy plane slots [read_off, read_off + n_reads);
- * read_off is a multiple of 4. umi ids are < n_umi (dense, order of first appearance). frag ids are
- * locus-level fragment slots < n_frag, grouped by barcode: the fragments of barcode u occupy one
- * contiguous slot range, ranges ordered by u, each fragment's slot fixed by its first appearance
- * within the barcode; n_frag = number of distinct fragments (= allFrag, smCounter.py:483).
+/* One per locus, 32 bytes. Reads of locus l occupy plane slots [4*read_off4, 4*read_off4 + n_reads)
+ * (every locus starts on a 4-read boundary). Within the locus the reads are SORTED barcode-major:
+ * by barcode id, then by fragment slot, then by pileup order (stable), so a barcode's reads are one
+ * contiguous run, a fragment's reads are adjacent, and the first-seen mate still comes first
+ * (smCounter.py:468-479 depends on that order only within a fragment).
+ * umi ids are < n_umi (dense, order of first appearance in the pileup). frag ids are locus-level
+ * fragment slots < n_frag, grouped by barcode: the fragments of barcode u occupy one contiguous slot
+ * range, ranges ordered by u, each fragment's slot fixed by its first appearance within the barcode;
+ * n_frag = number of distinct fragments (= allFrag, smCounter.py:483).
+ * umi_start[umi_off + u], u = 0..n_umi, is the index (relative to the locus) of barcode u's first read;
+ * the last entry equals n_reads.
  * Base qualities are Phred values <= 126 (BAM holds 0..93); larger bytes are clamped to 126. */
 typedef struct smc_locus {
-    int64_t read_off;
+    uint32_t read_off4; /* first plane slot / 4 */
+    uint32_t umi_off;   /* first entry of this locus in the umi_start array */
     int32_t n_reads;
     int32_t n_umi;
     int32_t n_frag;
@@ -168,19 +175,19 @@ int smc_plan_info(const smc_plan* plan, int32_t* n_launches, int64_t* scratch_by
 int smc_plan_set_timing(smc_plan* plan, int slots);
 int smc_plan_kernel_ms(smc_plan* plan, float* avg_ms, int32_t* n_samples, int64_t* n_loci, int64_t* n_reads);
 
-/* Run the hot path over the batch. meta/umi/frag/dist and rows are DEVICE pointers
- * (n_slots x uint32 each; rows n_loci x smc_row). `stream` is a hipStream_t (NULL = default
+/* Run the hot path over the batch. meta/umi/frag/dist, umi_start and rows are DEVICE pointers
+ * (planes n_slots x uint32 each; umi_start sum(n_umi + 1) x uint32; rows n_loci x smc_row). `stream` is a hipStream_t (NULL = default
  * stream). Asynchronous: returns after enqueueing. */
 int smc_plan_run(smc_plan* plan, const smc_params* params, const uint32_t* meta,
-                 const uint32_t* umi, const uint32_t* frag, const uint32_t* dist, smc_row* rows,
-                 void* stream);
+                 const uint32_t* umi, const uint32_t* frag, const uint32_t* dist,
+                 const uint32_t* umi_start, smc_row* rows, void* stream);
 
 /* Convenience for callers without their own device buffers: host pointers in, host rows out
  * (synchronous; does H2D, smc_plan_run, D2H). */
 int smc_call_batch_host(smc_ctx* ctx, const smc_params* params, const smc_locus* loci,
                         int64_t n_loci, const uint32_t* meta, const uint32_t* umi,
                         const uint32_t* frag, const uint32_t* dist, int64_t n_slots,
-                        smc_row* rows_out);
+                        const uint32_t* umi_start, int64_t n_umi_start, smc_row* rows_out);
 
 /* HIP-event timing helpers so a host language without HIP bindings can time the stream the
  * kernels run on. */

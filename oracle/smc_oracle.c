@@ -366,7 +366,8 @@ int smc_oracle_call_batch(const smc_params* P, const smc_locus* loci, int64_t n_
     for (int64_t l = 0; l < n_loci; ++l) {
         const smc_locus* L = &loci[l];
         if (L->n_alleles > SMC_MAX_ALLELES) return -1;
-        call_locus(P, L, meta + L->read_off, umi + L->read_off, frag + L->read_off, dist + L->read_off, &rows[l], NULL);
+        call_locus(P, L, meta + 4 * (int64_t)L->read_off4, umi + 4 * (int64_t)L->read_off4, frag + 4 * (int64_t)L->read_off4,
+                   dist + 4 * (int64_t)L->read_off4, &rows[l], NULL);
     }
     return 0;
 }
@@ -377,8 +378,8 @@ int smc_oracle_call_batch_ex(const smc_params* P, const smc_locus* loci, int64_t
     for (int64_t l = 0; l < n_loci; ++l) {
         const smc_locus* L = &loci[l];
         if (L->n_alleles > SMC_MAX_ALLELES) return -1;
-        call_locus(P, L, meta + L->read_off, umi + L->read_off, frag + L->read_off, dist + L->read_off, &rows[l],
-                   fragile ? &fragile[l] : NULL);
+        call_locus(P, L, meta + 4 * (int64_t)L->read_off4, umi + 4 * (int64_t)L->read_off4, frag + 4 * (int64_t)L->read_off4,
+                   dist + 4 * (int64_t)L->read_off4, &rows[l], fragile ? &fragile[l] : NULL);
     }
     return 0;
 }

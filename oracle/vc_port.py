@@ -228,7 +228,7 @@ def call_batch(db, params, n_cpu=1, loci=None, pool=None):
     tasks = []
     for l in idx:
         L = db.loci[l]
-        o, n = int(L["read_off"]), int(L["n_reads"])
+        o, n = 4 * int(L["read_off4"]), int(L["n_reads"])
         tasks.append((db.meta[o:o + n], db.umi[o:o + n], db.frag[o:o + n], db.dist[o:o + n], int(L["ref_allele"]),
                       int(L["n_alleles"]), int(L["snp_mask"]), params.minBQ, params.minMQ, params.mtDrop,
                       params.primerDist, params.ds, params.smt))

@@ -50,11 +50,11 @@ def load():
     L.smc_plan_destroy.argtypes = [vp]
     L.smc_plan_destroy.restype = None
     L.smc_plan_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i64)]
-    L.smc_plan_run.argtypes = [vp, ctypes.POINTER(abi.SmcParams), vp, vp, vp, vp, vp, vp]
+    L.smc_plan_run.argtypes = [vp, ctypes.POINTER(abi.SmcParams), vp, vp, vp, vp, vp, vp, vp]
     L.smc_plan_set_timing.argtypes = [vp, ctypes.c_int]
     L.smc_plan_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(i32), ctypes.POINTER(i64),
                                      ctypes.POINTER(i64)]
-    L.smc_call_batch_host.argtypes = [vp, ctypes.POINTER(abi.SmcParams), vp, i64, vp, vp, vp, vp, i64, vp]
+    L.smc_call_batch_host.argtypes = [vp, ctypes.POINTER(abi.SmcParams), vp, i64, vp, vp, vp, vp, i64, vp, i64, vp]
     L.smc_event_create.argtypes = [ctypes.POINTER(vp)]
     L.smc_event_record.argtypes = [vp, vp]
     L.smc_event_elapsed_ms.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_float)]

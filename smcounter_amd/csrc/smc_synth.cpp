@@ -71,8 +71,9 @@ int64_t smc_synth_slots(const smc_synth_cfg* c, int64_t lo, int64_t hi) {
 
 // extra[l]: bit0 insertion allele present, bit1 deletion-start allele present, bit2 insertion got
 // the lower id (6).  Strings are rebuilt on the host from pos (smcounter_amd/synth.py).
+// umi_start: (hi-lo) * (n_umi + 1) entries
 int smc_synth_generate(const smc_synth_cfg* c, int64_t lo, int64_t hi, uint32_t* meta, uint32_t* umi, uint32_t* frag,
-                       uint32_t* dist, smc_locus* loci, uint8_t* extra, int nthreads) {
+                       uint32_t* dist, uint32_t* umi_start, smc_locus* loci, uint8_t* extra, int nthreads) {
     const int U = c->n_umi, B = c->rpb, R = U * B;
     const int64_t stride = (R + 3) / 4 * 4;
     const int f0 = std::max(1, (int)llround(B / (1.0 + c->p_overlap)));
@@ -176,6 +177,19 @@ int smc_synth_generate(const smc_synth_cfg* c, int64_t lo, int64_t hi, uint32_t*
             for (int i = 0; i < R; ++i) out[i].frag += (uint32_t)ubase[out[i].umi];
             const int ins_id = first_ins < first_dst ? 6 : 7;
             const int dst_id = first_dst < first_ins ? 6 : (first_ins <= R ? 7 : 6);
+            // batch layout: reads sorted barcode-major (barcode, fragment slot, pileup order)
+            {
+                std::vector<int> idx(R);
+                for (int i = 0; i < R; ++i) idx[i] = i;
+                std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return out[x].frag < out[y].frag; });
+                std::vector<Rd> tmp(R);
+                for (int i = 0; i < R; ++i) tmp[i] = out[idx[i]];
+                out.swap(tmp);
+                uint32_t* us = umi_start + (l - lo) * (int64_t)(U + 1);
+                for (int u = 0; u <= U; ++u) us[u] = 0;
+                for (int i = 0; i < R; ++i) us[out[i].umi + 1]++;
+                for (int u = 0; u < U; ++u) us[u + 1] += us[u];
+            }
             const int64_t off = (l - lo) * stride;
             for (int i = 0; i < R; ++i) {
                 Rd& r = out[i];
@@ -188,7 +202,8 @@ int smc_synth_generate(const smc_synth_cfg* c, int64_t lo, int64_t hi, uint32_t*
             }
             for (int64_t i = R; i < stride; ++i) meta[off + i] = umi[off + i] = frag[off + i] = dist[off + i] = 0;
             smc_locus& L = loci[l - lo];
-            L.read_off = off;
+            L.read_off4 = (uint32_t)(off / 4);
+            L.umi_off = (uint32_t)((l - lo) * (int64_t)(U + 1));
             L.n_reads = R;
             L.n_umi = U;
             L.n_frag = n_frag_total;

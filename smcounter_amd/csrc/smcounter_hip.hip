@@ -218,10 +218,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
     const smc_locus L = loci[blockIdx.x];
     const int li = order[blockIdx.x];
     const int n = L.n_reads, nU = L.n_umi, nF = L.n_frag, nA = L.n_alleles;
-    const uint4* meta4 = (const uint4*)(g_meta + L.read_off);
-    const uint4* umi4 = (const uint4*)(g_umi + L.read_off);
-    const uint4* frag4 = (const uint4*)(g_frag + L.read_off);
-    const uint4* dist4 = (const uint4*)(g_dist + L.read_off);
+    const uint4* meta4 = (const uint4*)(g_meta + 4ll * L.read_off4);
+    const uint4* umi4 = (const uint4*)(g_umi + 4ll * L.read_off4);
+    const uint4* frag4 = (const uint4*)(g_frag + 4ll * L.read_off4);
+    const uint4* dist4 = (const uint4*)(g_dist + 4ll * L.read_off4);
 
     // ---- carve LDS
     Hdr* H = (Hdr*)smem;
@@ -466,9 +466,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
     if (H->misc[M_RESOLVED] != H->misc[M_NINC]) {
         // Some read name has >= 3 included alignments on this locus (rare): redo the fragment table,
         // mark those fragments, resolve the others as above and replay the marked ones in read order.
-        const uint32_t* meta = g_meta + L.read_off;
-        const uint32_t* umi = g_umi + L.read_off;
-        const uint32_t* frag = g_frag + L.read_off;
+        const uint32_t* meta = g_meta + 4ll * L.read_off4;
+        const uint32_t* umi = g_umi + 4ll * L.read_off4;
+        const uint32_t* frag = g_frag + 4ll * L.read_off4;
         for (int i = tid; i < nF; i += BLOCK) { fmin[i] = 0xFFFFFFFFu; fmax[i] = 0u; }
         for (int a = tid; a < a_cap; a += BLOCK) tal[a * SMC_NT + SMC_T_CONCORD] = tal[a * SMC_NT + SMC_T_DISCORD] = 0;
         __syncthreads();
@@ -1187,11 +1187,10 @@ int smc_plan_create(smc_ctx* ctx, const smc_locus* loci, int64_t n_loci, smc_pla
     for (int c = 0; c < 5; ++c) { bins[c].cls = c; bins[c].a_cap = 8; bins[c].lds_bytes = 0; }
     for (int64_t l = 0; l < n_loci; ++l) {
         const smc_locus& L = loci[l];
-        if (L.n_alleles > SMC_MAX_ALLELES || L.n_reads < 0 || L.n_umi < 0 || L.n_frag < 0 || (L.read_off & 3) ||
-            L.n_reads >= (1 << 18)) {
+        if (L.n_alleles > SMC_MAX_ALLELES || L.n_reads < 0 || L.n_umi < 0 || L.n_frag < 0 || L.n_reads >= (1 << 18)) {
             delete p;
             return fail(SMC_E_INPUT, "smc_plan_create: locus " + std::to_string(l) +
-                                         " violates the layout contract (alleles<=64, reads<2^18, read_off%4==0)");
+                                         " violates the layout contract (alleles<=64, reads<2^18)");
         }
         const int a_cap = (L.n_alleles + 7) & ~7;
         const size_t need = host_hdr_bytes(a_cap < 8 ? 8 : a_cap) + table_bytes(L);
@@ -1286,10 +1285,10 @@ int smc_plan_info(const smc_plan* p, int32_t* n_launches, int64_t* scratch_bytes
 }
 
 int smc_plan_run(smc_plan* p, const smc_params* prm, const uint32_t* meta, const uint32_t* umi, const uint32_t* frag,
-                 const uint32_t* dist, smc_row* rows, void* stream) {
+                 const uint32_t* dist, const uint32_t* umi_start, smc_row* rows, void* stream) {
     if (!p || !prm) return fail(SMC_E_ARG, "smc_plan_run: NULL argument");
     if (p->n_loci == 0) return SMC_OK;
-    if (!meta || !umi || !frag || !dist || !rows) return fail(SMC_E_ARG, "smc_plan_run: NULL device pointer");
+    if (!meta || !umi || !frag || !dist || !umi_start || !rows) return fail(SMC_E_ARG, "smc_plan_run: NULL device pointer");
     HIPCHK(hipSetDevice(p->ctx->device));
     hipStream_t st = (hipStream_t)stream;
     KParams kp{prm->min_bq, prm->min_mq, prm->mt_drop, prm->primer_dist, prm->ds, prm->smt};
@@ -1318,30 +1317,32 @@ int smc_plan_run(smc_plan* p, const smc_params* prm, const uint32_t* meta, const
 }
 
 int smc_call_batch_host(smc_ctx* ctx, const smc_params* prm, const smc_locus* loci, int64_t n_loci, const uint32_t* meta,
-                        const uint32_t* umi, const uint32_t* frag, const uint32_t* dist, int64_t n_slots, smc_row* rows_out) {
+                        const uint32_t* umi, const uint32_t* frag, const uint32_t* dist, int64_t n_slots,
+                        const uint32_t* umi_start, int64_t n_umi_start, smc_row* rows_out) {
     if (!ctx || !prm || (n_loci && (!loci || !rows_out))) return fail(SMC_E_ARG, "smc_call_batch_host: NULL argument");
     if (n_loci == 0) return SMC_OK;
     HIPCHK(hipSetDevice(ctx->device));
     smc_plan* plan = nullptr;
     int rc = smc_plan_create(ctx, loci, n_loci, &plan);
     if (rc) return rc;
-    uint32_t* d[4] = {nullptr, nullptr, nullptr, nullptr};
-    const uint32_t* h[4] = {meta, umi, frag, dist};
+    uint32_t* d[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    const uint32_t* h[5] = {meta, umi, frag, dist, umi_start};
+    const int64_t hn[5] = {n_slots, n_slots, n_slots, n_slots, n_umi_start};
     smc_row* d_rows = nullptr;
-    const size_t pb = sizeof(uint32_t) * (size_t)(n_slots > 0 ? n_slots : 1);
+
     auto cleanup = [&]() {
         for (auto q : d) (void)hipFree(q);
         (void)hipFree(d_rows);
         smc_plan_destroy(plan);
     };
-    for (int k = 0; k < 4; ++k) {
-        hipError_t e = hipMalloc(&d[k], pb);
-        if (e == hipSuccess && n_slots > 0) e = hipMemcpy(d[k], h[k], sizeof(uint32_t) * (size_t)n_slots, hipMemcpyHostToDevice);
+    for (int k = 0; k < 5; ++k) {
+        hipError_t e = hipMalloc(&d[k], sizeof(uint32_t) * (size_t)(hn[k] > 0 ? hn[k] : 1));
+        if (e == hipSuccess && hn[k] > 0) e = hipMemcpy(d[k], h[k], sizeof(uint32_t) * (size_t)hn[k], hipMemcpyHostToDevice);
         if (e != hipSuccess) { cleanup(); return fail(SMC_E_HIP, std::string("plane upload: ") + hipGetErrorString(e)); }
     }
     hipError_t e = hipMalloc(&d_rows, sizeof(smc_row) * (size_t)n_loci);
     if (e != hipSuccess) { cleanup(); return fail(SMC_E_HIP, std::string("rows alloc: ") + hipGetErrorString(e)); }
-    rc = smc_plan_run(plan, prm, d[0], d[1], d[2], d[3], d_rows, nullptr);
+    rc = smc_plan_run(plan, prm, d[0], d[1], d[2], d[3], d[4], d_rows, nullptr);
     if (rc == SMC_OK) {
         e = hipDeviceSynchronize();
         if (e == hipSuccess) e = hipMemcpy(rows_out, d_rows, sizeof(smc_row) * (size_t)n_loci, hipMemcpyDeviceToHost);

@@ -36,18 +36,19 @@ class Engine(object):
         cp = abi.c_params(params)
         loci = np.ascontiguousarray(db.loci)
         planes = [np.ascontiguousarray(x, np.uint32) for x in (db.meta, db.umi, db.frag, db.dist)]
+        us = np.ascontiguousarray(db.umi_start, np.uint32)
         _lib.check(self.L.smc_call_batch_host(
             self.ctx, ctypes.byref(cp), loci.ctypes.data, db.n_loci,
             planes[0].ctypes.data, planes[1].ctypes.data, planes[2].ctypes.data, planes[3].ctypes.data,
-            db.n_slots, rows.ctypes.data), "smc_call_batch_host")
+            db.n_slots, us.ctypes.data, len(us), rows.ctypes.data), "smc_call_batch_host")
         return rows
 
-    # ---- resident path: planes live in HBM (torch tensors), a plan is reused across runs
+    # ---- resident path: the four planes + umi_start live in HBM (torch tensors), a plan is reused
     def upload(self, db: DeviceBatch):
         import torch
         dev = torch.device("cuda", self.device)
         return [torch.from_numpy(np.ascontiguousarray(x).view(np.int32)).to(dev)
-                for x in (db.meta, db.umi, db.frag, db.dist)]
+                for x in (db.meta, db.umi, db.frag, db.dist, db.umi_start)]
 
     def make_plan(self, loci: np.ndarray):
         loci = np.ascontiguousarray(loci)
@@ -79,8 +80,8 @@ class Plan(object):
         st = stream if stream is not None else torch.cuda.current_stream(self.eng.device)
         cp = abi.c_params(params)
         _lib.check(self.eng.L.smc_plan_run(self.h, ctypes.byref(cp), planes[0].data_ptr(), planes[1].data_ptr(),
-                                           planes[2].data_ptr(), planes[3].data_ptr(), rows.data_ptr(),
-                                           ctypes.c_void_p(st.cuda_stream)), "smc_plan_run")
+                                           planes[2].data_ptr(), planes[3].data_ptr(), planes[4].data_ptr(),
+                                           rows.data_ptr(), ctypes.c_void_p(st.cuda_stream)), "smc_plan_run")
         return rows
 
     def set_timing(self, slots: int):

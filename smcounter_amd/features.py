@@ -31,7 +31,7 @@ import numpy as np
 from .params import VcParams
 from .pileup import (F_READ1, F_READ2, F_REVERSE, MAX_ALLELES, PileupBatch, BASE_ALLELES)
 
-LOCUS_DTYPE = np.dtype([("read_off", "<i8"), ("n_reads", "<i4"), ("n_umi", "<i4"),
+LOCUS_DTYPE = np.dtype([("read_off4", "<u4"), ("umi_off", "<u4"), ("n_reads", "<i4"), ("n_umi", "<i4"),
                         ("n_frag", "<i4"), ("ref_allele", "u1"), ("n_alleles", "u1"),
                         ("flags", "<u2"), ("snp_mask", "<u8")])
 assert LOCUS_DTYPE.itemsize == 32
@@ -55,6 +55,7 @@ class DeviceBatch:
     umi: np.ndarray
     frag: np.ndarray
     dist: np.ndarray
+    umi_start: np.ndarray     # uint32[sum(n_umi + 1)]: per locus, first read of each barcode (+ n_reads)
     # host-only context for formatting rows
     chrom: List[str]
     pos: np.ndarray
@@ -74,7 +75,10 @@ class DeviceBatch:
         return int(self.loci["n_reads"].sum())
 
     def input_bytes(self) -> int:
-        return 16 * self.n_slots + self.loci.nbytes
+        return 16 * self.n_slots + self.loci.nbytes + self.umi_start.nbytes
+
+    def read_off(self, l: int) -> int:
+        return 4 * int(self.loci["read_off4"][l])
 
 
 def ref_allele_id(ref: str, table: List[str]) -> int:
@@ -159,20 +163,38 @@ def extract_features(pb: PileupBatch, params: VcParams) -> DeviceBatch:
         base_local = excl - locus_first[kl]
         slot = (base_local[inv] + pb.frag.astype(np.int64)).astype(np.uint32)
 
-    # --- padded CSR: each locus starts on a READ_ALIGN boundary
+    # --- padded CSR: each locus starts on a READ_ALIGN boundary; within the locus reads are sorted
+    # barcode-major (barcode, fragment slot, pileup order): a stable sort, so the order of the reads
+    # of one fragment - the only order vc() depends on - is kept
     padded = (lens + READ_ALIGN - 1) // READ_ALIGN * READ_ALIGN
     off = np.zeros(n_loci + 1, np.int64)
     off[1:] = np.cumsum(padded)
     n_slots = int(off[-1])
-    dst = (off[:-1][locus_of] + (np.arange(n, dtype=np.int64) - pb.read_off[:-1][locus_of])) \
-        if n else np.zeros(0, np.int64)
+    if n:
+        order = np.lexsort((np.arange(n), slot.astype(np.int64), locus_of))     # last key is primary
+        dst = np.empty(n, np.int64)
+        dst[order] = off[:-1][locus_of[order]] + (np.arange(n, dtype=np.int64) - pb.read_off[:-1][locus_of[order]])
+    else:
+        dst = np.zeros(0, np.int64)
 
     def plane(src):
         out = np.zeros(n_slots, np.uint32)
         out[dst] = src
         return out
 
-    loci["read_off"] = off[:-1]
+    # first read of every barcode, relative to its locus (+ a closing entry per locus)
+    umi_off = np.zeros(n_loci + 1, np.int64)
+    umi_off[1:] = np.cumsum(n_umi + 1)
+    umi_start = np.zeros(int(umi_off[-1]), np.uint32)
+    if n:
+        cnt = np.zeros(int(umi_off[-1]), np.int64)
+        np.add.at(cnt, umi_off[:-1][locus_of] + pb.umi.astype(np.int64) + 1, 1)
+        # cumulative within each locus: entry u+1 accumulates reads of barcodes <= u
+        csum = np.cumsum(cnt)
+        base = np.repeat(csum[umi_off[:-1]], n_umi + 1)
+        umi_start[:] = (csum - base).astype(np.uint32)
+    loci["read_off4"] = off[:-1] // READ_ALIGN
+    loci["umi_off"] = umi_off[:-1]
     loci["n_reads"] = lens
     loci["n_umi"] = n_umi
     loci["n_frag"] = n_frag
@@ -191,5 +213,5 @@ def extract_features(pb: PileupBatch, params: VcParams) -> DeviceBatch:
         loci["snp_mask"][l] = mask
 
     return DeviceBatch(loci=loci, meta=plane(meta), umi=plane(pb.umi), frag=plane(slot),
-                       dist=plane(dist), chrom=list(pb.chrom), pos=pb.pos.copy(),
+                       dist=plane(dist), umi_start=umi_start, chrom=list(pb.chrom), pos=pb.pos.copy(),
                        ref=list(pb.ref), alleles=[list(t) for t in pb.alleles])

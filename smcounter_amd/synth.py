@@ -433,11 +433,13 @@ def generate_native(cfg: SynthConfig, lo: int = 0, hi: int = None, params=None, 
     n = hi - lo
     slots = lib.smc_synth_slots(ctypes.byref(c), ctypes.c_int64(lo), ctypes.c_int64(hi))
     planes = [np.empty(slots, np.uint32) for _ in range(4)]
+    umi_start = np.zeros(n * (cfg.n_umi + 1), np.uint32)
     loci = np.zeros(n, LOCUS_DTYPE)
     extra = np.zeros(n, np.uint8)
     nthreads = nthreads or min(32, os.cpu_count() or 1)
     rc = lib.smc_synth_generate(ctypes.byref(c), ctypes.c_int64(lo), ctypes.c_int64(hi),
                                 *[p.ctypes.data_as(ctypes.c_void_p) for p in planes],
+                                umi_start.ctypes.data_as(ctypes.c_void_p),
                                 loci.ctypes.data_as(ctypes.c_void_p), extra.ctypes.data_as(ctypes.c_void_p),
                                 ctypes.c_int(nthreads))
     assert rc == 0
@@ -456,4 +458,4 @@ def generate_native(cfg: SynthConfig, lo: int = 0, hi: int = None, params=None, 
         else:
             alleles[l] = base + [del_s]
     return DeviceBatch(loci=loci, meta=planes[0], umi=planes[1], frag=planes[2], dist=planes[3],
-                       chrom=[cfg.chrom] * n, pos=pos, ref=ref, alleles=alleles)
+                       umi_start=umi_start, chrom=[cfg.chrom] * n, pos=pos, ref=ref, alleles=alleles)

@@ -105,7 +105,7 @@ def test_bad_ids_are_reported_not_crashed(engine0):
     cfg = synth.CONFIGS["C2"]
     P = synth.params_for(cfg)
     db = synth.generate_native(cfg, 0, 8, P)
-    db.umi[int(db.loci["read_off"][3]) + 5] = 1000       # out of the declared range
+    db.umi[db.read_off(3) + 5] = 1000       # out of the declared range
     got = engine0.call_batch_host(db, P)
     assert got["status"][3] & abi.ST_BAD_INPUT
     assert (got["status"][[0, 1, 2, 4, 5, 6, 7]] == 0).all()

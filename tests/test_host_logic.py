@@ -37,42 +37,45 @@ def test_threshold_and_smt_and_ds():
     assert VcParams(mtDepth=10, maxMT=7).ds == 7
 
 
-def test_feature_extraction_matches_native_generator():
-    """The numpy feature extraction (a1) and the C++ generator's own arithmetic agree on what a
-    read's flags / distances are: regenerate the same primary facts through both is not possible
-    (different RNGs), so check the invariants of the layout instead."""
+def _check_layout(db, l):
+    """Reads of a locus: sorted barcode-major, fragment slots contiguous per barcode, umi_start consistent."""
+    o, n = db.read_off(l), int(db.loci["n_reads"][l])
+    u, f = db.umi[o:o + n].astype(np.int64), db.frag[o:o + n].astype(np.int64)
+    assert (np.diff(u) >= 0).all() and (np.diff(f) >= 0).all()
+    nu = int(db.loci["n_umi"][l])
+    us = db.umi_start[int(db.loci["umi_off"][l]):int(db.loci["umi_off"][l]) + nu + 1]
+    assert us[0] == 0 and us[-1] == n
+    tot = 0
+    for uu in range(nu):
+        run = f[us[uu]:us[uu + 1]]
+        assert (u[us[uu]:us[uu + 1]] == uu).all() and len(run) > 0
+        assert run.min() == tot and np.array_equal(np.unique(run), np.arange(tot, run.max() + 1))
+        tot = int(run.max()) + 1
+    assert tot == db.loci["n_frag"][l]
+
+
+def test_layout_of_native_generator_and_feature_extraction():
     cfg = synth.CONFIGS["C2"]
     db = synth.generate_native(cfg, 0, 50)
-    assert (db.loci["read_off"] % 4 == 0).all()
     assert (db.loci["n_reads"] == cfg.depth).all() and (db.loci["n_umi"] == cfg.n_umi).all()
     for l in range(db.n_loci):
-        o, n = int(db.loci["read_off"][l]), int(db.loci["n_reads"][l])
-        u, f = db.umi[o:o + n], db.frag[o:o + n]
-        # ids are dense in order of first appearance
-        first = {}
-        for x in u:
-            first.setdefault(int(x), len(first))
-        assert list(first.keys()) == list(range(len(first)))
-        tot = 0
-        for uu in range(len(first)):
-            ff = f[u == uu]
-            seen = {}
-            for x in ff:
-                seen.setdefault(int(x), len(seen))
-            # fragment slots: barcode-major, contiguous, in order of first appearance
-            assert list(seen.keys()) == list(range(tot, tot + len(seen)))
-            tot += len(seen)
-        assert tot == db.loci["n_frag"][l]
+        _check_layout(db, l)
     pb = synth.generate(cfg, 0, 20)
     db2 = features.extract_features(pb, synth.params_for(cfg))
     assert (db2.loci["n_umi"] == cfg.n_umi).all() and db2.n_reads == 20 * cfg.depth
     for l in range(db2.n_loci):
-        o, n = int(db2.loci["read_off"][l]), int(db2.loci["n_reads"][l])
+        _check_layout(db2, l)
+        # the sort is stable: reads of one fragment keep their pileup order
         s_ = pb.locus_slice(l)
-        u, fl, slot = pb.umi[s_], pb.frag[s_], db2.frag[o:o + n]
-        nfr = [int(fl[u == uu].max()) + 1 for uu in range(int(u.max()) + 1)]
-        base = np.concatenate([[0], np.cumsum(nfr)])
-        assert (slot == base[u] + fl).all() and base[-1] == db2.loci["n_frag"][l]
+        o, n = db2.read_off(l), int(db2.loci["n_reads"][l])
+        key = pb.umi[s_].astype(np.int64) * 100000 + pb.frag[s_]
+        order = np.argsort(key, kind="stable")
+        assert np.array_equal(db2.meta[o:o + n] & 0xff, pb.allele[s_][order])
+    pbs, _ = synth.generate_stress(40, 5)
+    dbs = features.extract_features(pbs, VcParams(mtDepth=100, rpb=2))
+    for l in range(dbs.n_loci):
+        if dbs.loci["n_reads"][l]:
+            _check_layout(dbs, l)
 
 
 def test_unflagged_first_read_is_an_error():
