@@ -26,6 +26,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -194,6 +195,78 @@ typedef unsigned long long lmask;
 #define LANES(m) __builtin_amdgcn_inverse_ballot_w64(m)
 #define ADDM(acc, m) asm volatile("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(acc) : "s"((lmask)(m)) : "vcc")   // qualities with an LDS-resident error probability; rarer ones read the global table
 
+
+// ---- E stage shared by both locus kernels: ranking and candidates (smCounter.py:534-555), one thread.
+// R points at a zeroed row staged in LDS; misc[] holds the M_* counters.
+__device__ __forceinline__ void finish_row(smc_row* R, const smc_locus& L, int li, int n, int nF, int used, bool downsampled,
+                                           double fxscale, const uint32_t* misc, const uint32_t* tal,
+                                           const unsigned long long* pifx, const uint32_t* mtc, const uint32_t* strong,
+                                           uint32_t* flt_list) {
+    const int nA = L.n_alleles;
+    const unsigned long long touched = ((unsigned long long)misc[M_TOUCH_HI] << 32) | misc[M_TOUCH_LO];
+    const int nkeys = __popcll(touched);
+    const double inv = 1.0 / fxscale;
+    auto PI = [&](int a) { return (double)(long long)pifx[a] * inv; };
+    auto rank = [&](int a) {
+        const int r8[6] = {0, 5, 6, 2, 7, 4}, r32[6] = {0, 21, 6, 2, 15, 20};
+        return a < 6 ? (nkeys <= 5 ? r8[a] : r32[a]) : 64 + a;
+    };
+    int best = -1, second = -1;
+    for (int pass = 0; pass < 2; ++pass) {
+        int pick = -1;
+        double ppi = 0.0;
+        for (int a = 0; a < nA; ++a) {
+            if (!((touched >> a) & 1ull) || a == best) continue;
+            const double v = PI(a);
+            if (pick < 0 || v > ppi || (v == ppi && rank(a) < rank(pick))) { pick = a; ppi = v; }
+        }
+        if (pass == 0) best = pick; else second = pick;
+    }
+    R->status = downsampled ? SMC_ST_DOWNSAMPLED : SMC_ST_OK;
+    R->n_touched = nkeys;
+    R->cvg = n;
+    R->all_frag = nF;
+    R->all_mt = misc[M_ALLMT];
+    R->used_frag = misc[M_USEDFRAG];
+    R->used_mt = used;
+    R->mt3 = misc[M_MT3]; R->mt5 = misc[M_MT5]; R->mt7 = misc[M_MT7]; R->mt10 = misc[M_MT10];
+    R->max_allele = best; R->second_allele = second;
+    R->touched_mask = touched;
+    for (int k = 0; k < 4; ++k) {
+        R->dp[k] = tal[k * SMC_NT + SMC_T_CNT];
+        R->umt[k] = mtc[k];
+        R->vsm[k] = strong[k];
+        R->pi[k] = PI(k);
+    }
+    const int ref = L.ref_allele;
+    if (ref < nA) for (int k = 0; k < SMC_NT; ++k) R->ref_tal[k] = tal[ref * SMC_NT + k];
+    auto fill = [&](smc_cand& C, int a) {
+        C.allele = a;
+        C.p_sb = C.p_r1 = C.p_r2 = C.p_pr = NAN;
+        if (a < 0) return;
+        C.pi = PI(a);
+        C.vdp = tal[a * SMC_NT + SMC_T_CNT];
+        C.vmt = mtc[a];
+        C.vsm = strong[a];
+        for (int k = 0; k < SMC_NT; ++k) C.tal[k] = tal[a * SMC_NT + k];
+    };
+    auto filterable = [&](int a) { return ((L.snp_mask >> a) & 1ull) || a != GAP_ID; };  // SNP or INDEL
+    const int alt = best == ref ? second : best;                                   // :541
+    fill(R->cand[0], alt);
+    if (alt >= 0 && R->cand[0].pi >= 5 && filterable(alt)) R->cand[0].flt_applied = 1;   // :549
+    const double mf1 = best >= 0 ? 1.0 * mtc[best] / used : 0.0;
+    const double mf2 = second >= 0 ? 1.0 * mtc[second] / used : 0.0;
+    if (best >= 0 && second >= 0 && best != ref && second != ref && mf1 >= 0.45 && mf2 >= 0.45) {   // :555
+        R->biallelic = 1;
+        fill(R->cand[1], second);
+        if (R->cand[1].pi >= 5 && filterable(second)) R->cand[1].flt_applied = 1;   // :563
+    } else {
+        fill(R->cand[1], -1);
+    }
+    // loci whose candidate(s) go through filterVariants are queued for k_filter_loci
+    if (R->cand[0].flt_applied || R->cand[1].flt_applied) flt_list[1 + atomicAdd(&flt_list[0], 1u)] = (uint32_t)li;
+}
+
 // ------------------------------------------------------------------------------------------
 // kernel 1: scan + group + score + rank
 // ------------------------------------------------------------------------------------------
@@ -211,12 +284,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
     KParams P, const smc_locus* __restrict__ loci, const int* __restrict__ order, int a_cap,
     const uint32_t* __restrict__ g_meta, const uint32_t* __restrict__ g_umi, const uint32_t* __restrict__ g_frag,
     const uint32_t* __restrict__ g_dist, const double* __restrict__ g_lut, smc_row* __restrict__ rows,
-    uint8_t* __restrict__ scratch, const int64_t* __restrict__ scratch_off, uint32_t* __restrict__ flt_list) {
+    uint8_t* __restrict__ scratch, const int64_t* __restrict__ scratch_off, uint32_t* __restrict__ flt_list,
+    const uint8_t* __restrict__ redo_flag) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     // `loci` is this bin's descriptor array in launch order; order[] maps back to the batch index
-    const smc_locus L = loci[blockIdx.x];
     const int li = order[blockIdx.x];
+    // when the sorted-stream kernel ran first, only the loci it handed over are processed here
+    if (redo_flag != nullptr && !redo_flag[li]) return;
+    const smc_locus L = loci[blockIdx.x];
     const int n = L.n_reads, nU = L.n_umi, nF = L.n_frag, nA = L.n_alleles;
     const uint4* meta4 = (const uint4*)(g_meta + 4ll * L.read_off4);
     const uint4* umi4 = (const uint4*)(g_umi + 4ll * L.read_off4);
@@ -888,71 +964,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         if (SMC_ABLATE == 4) return;
 
         // ---- E: ranking and candidates (:534-555), one thread
-        if (tid == 0) {
-            smc_row* R = rowst;   // zeroed in S0
-            const unsigned long long touched = ((unsigned long long)H->misc[M_TOUCH_HI] << 32) | H->misc[M_TOUCH_LO];
-            const int nkeys = __popcll(touched);
-            const double inv = 1.0 / fxscale;
-            auto PI = [&](int a) { return (double)(long long)pifx[a] * inv; };
-            auto rank = [&](int a) {
-                const int r8[6] = {0, 5, 6, 2, 7, 4}, r32[6] = {0, 21, 6, 2, 15, 20};
-                return a < 6 ? (nkeys <= 5 ? r8[a] : r32[a]) : 64 + a;
-            };
-            int best = -1, second = -1;
-            for (int pass = 0; pass < 2; ++pass) {
-                int pick = -1;
-                double ppi = 0.0;
-                for (int a = 0; a < nA; ++a) {
-                    if (!((touched >> a) & 1ull) || a == best) continue;
-                    const double v = PI(a);
-                    if (pick < 0 || v > ppi || (v == ppi && rank(a) < rank(pick))) { pick = a; ppi = v; }
-                }
-                if (pass == 0) best = pick; else second = pick;
-            }
-            R->status = ((int)n_bc > P.ds) ? SMC_ST_DOWNSAMPLED : SMC_ST_OK;
-            R->n_touched = nkeys;
-            R->cvg = n;
-            R->all_frag = nF;
-            R->all_mt = H->misc[M_ALLMT];
-            R->used_frag = H->misc[M_USEDFRAG];
-            R->used_mt = used;
-            R->mt3 = H->misc[M_MT3]; R->mt5 = H->misc[M_MT5]; R->mt7 = H->misc[M_MT7]; R->mt10 = H->misc[M_MT10];
-            R->max_allele = best; R->second_allele = second;
-            R->touched_mask = touched;
-            for (int k = 0; k < 4; ++k) {
-                R->dp[k] = tal[k * SMC_NT + SMC_T_CNT];
-                R->umt[k] = mtc[k];
-                R->vsm[k] = strong[k];
-                R->pi[k] = PI(k);
-            }
-            const int ref = L.ref_allele;
-            if (ref < nA) for (int k = 0; k < SMC_NT; ++k) R->ref_tal[k] = tal[ref * SMC_NT + k];
-            auto fill = [&](smc_cand& C, int a) {
-                C.allele = a;
-                C.p_sb = C.p_r1 = C.p_r2 = C.p_pr = NAN;
-                if (a < 0) return;
-                C.pi = PI(a);
-                C.vdp = tal[a * SMC_NT + SMC_T_CNT];
-                C.vmt = mtc[a];
-                C.vsm = strong[a];
-                for (int k = 0; k < SMC_NT; ++k) C.tal[k] = tal[a * SMC_NT + k];
-            };
-            auto filterable = [&](int a) { return ((L.snp_mask >> a) & 1ull) || a != GAP_ID; };  // SNP or INDEL
-            const int alt = best == ref ? second : best;                                   // :541
-            fill(R->cand[0], alt);
-            if (alt >= 0 && R->cand[0].pi >= 5 && filterable(alt)) R->cand[0].flt_applied = 1;   // :549
-            const double mf1 = best >= 0 ? 1.0 * mtc[best] / used : 0.0;
-            const double mf2 = second >= 0 ? 1.0 * mtc[second] / used : 0.0;
-            if (best >= 0 && second >= 0 && best != ref && second != ref && mf1 >= 0.45 && mf2 >= 0.45) {   // :555
-                R->biallelic = 1;
-                fill(R->cand[1], second);
-                if (R->cand[1].pi >= 5 && filterable(second)) R->cand[1].flt_applied = 1;   // :563
-            } else {
-                fill(R->cand[1], -1);
-            }
-            // loci whose candidate(s) go through filterVariants are queued for k_filter_loci
-            if (R->cand[0].flt_applied || R->cand[1].flt_applied) flt_list[1 + atomicAdd(&flt_list[0], 1u)] = (uint32_t)li;
-        }
+        if (tid == 0)
+            finish_row(rowst, L, li, n, nF, used, (int)n_bc > P.ds, fxscale, H->misc, tal, pifx, mtc, strong, flt_list);
         __syncthreads();
         const uint32_t* src = (const uint32_t*)rowst;
         uint32_t* dst = (uint32_t*)out;
@@ -960,6 +973,478 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         STAMP(9);
         STAMP_FLUSH();
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// kernel 1s: the sorted-stream locus kernel - one wavefront per locus, no atomics on the read path
+// ------------------------------------------------------------------------------------------
+// The batch contract sorts a locus's reads barcode-major (barcode, fragment slot, pileup order), so a
+// barcode is one contiguous run of reads and the reads of a fragment are adjacent, first-seen mate
+// first.  Lane groups of G lanes walk one barcode each, G reads per step: the mate merge
+// (smCounter.py:468-479) is a compare with the previous lane, per-fragment terms accumulate in lane
+// registers and are reduced across the group once per barcode; per-barcode records go to a 64-entry LDS
+// buffer and the calProb arithmetic then runs one lane per barcode.  Barcodes holding an allele other
+// than the reference are re-walked for per-allele products.  A fragment with >= 3 reads on the locus
+// (re-created fragments need a sequential replay) or a barcode with > 4 alleles sends the whole locus
+// to the table-based kernel k_call_loci instead (redo_flag); nothing is written for it here.
+struct URec {
+    double rightP, prod_ref;
+    uint32_t mlo, mhi;
+    int nf, cnt_ref;
+    uint32_t rb, re;
+    uint32_t in_bc, pad;
+};
+#define UB 64
+#define PK_NONE 0xFFFFFFFFu
+
+__device__ __forceinline__ uint32_t lds_sorted_bytes(int a_cap) {
+    return (uint32_t)(sizeof(Hdr) + a_cap * 64 + sizeof(smc_row) + 128 * 8 + UB * sizeof(URec) + UB * 4);
+}
+
+__global__ __launch_bounds__(WAVE) void k_call_sorted(
+    KParams P, const smc_locus* __restrict__ loci, const int* __restrict__ order, int a_cap,
+    const uint32_t* __restrict__ g_meta, const uint32_t* __restrict__ g_umi, const uint32_t* __restrict__ g_frag,
+    const uint32_t* __restrict__ g_dist, const uint32_t* __restrict__ g_umi_start, const double* __restrict__ g_lut,
+    smc_row* __restrict__ rows, uint32_t* __restrict__ flt_list, uint8_t* __restrict__ redo_flag) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const smc_locus L = loci[blockIdx.x];
+    const int li = order[blockIdx.x];
+    const int n = L.n_reads, nU = L.n_umi, nF = L.n_frag, nA = L.n_alleles;
+    const uint32_t refa = L.ref_allele;
+    const uint32_t* meta = g_meta + 4ll * L.read_off4;
+    const uint32_t* umi = g_umi + 4ll * L.read_off4;
+    const uint32_t* frag = g_frag + 4ll * L.read_off4;
+    const uint32_t* dist = g_dist + 4ll * L.read_off4;
+    const uint32_t* ustart = g_umi_start + L.umi_off;
+
+    Hdr* H = (Hdr*)smem;
+    uint32_t* tal = (uint32_t*)(smem + sizeof(Hdr));
+    unsigned long long* pifx = (unsigned long long*)(tal + a_cap * SMC_NT);
+    uint32_t* mtc = (uint32_t*)(pifx + a_cap);
+    uint32_t* strong = mtc + a_cap;
+    smc_row* rowst = (smc_row*)(strong + a_cap);
+    double* lut = (double*)(rowst + 1);
+    URec* urec = (URec*)(lut + LUT_N);
+    uint32_t* clist = (uint32_t*)(urec + UB);
+    {
+        uint32_t* z = (uint32_t*)smem;
+        const int nz = (int)((sizeof(Hdr) + a_cap * 64 + sizeof(smc_row)) / 4);
+        for (int i = lane; i < nz; i += WAVE) z[i] = 0;
+        for (int i = lane; i < LUT_N; i += WAVE) lut[i] = i == (int)PIDX_UNPAIRED ? 0.1 : g_lut[i];
+    }
+    __syncthreads();
+
+    // lanes per barcode (a function of the locus only): each lane takes a quad of reads per step and a
+    // barcode should take a handful of steps - few barcode starts, whose first loads are not prefetched
+    int G = 1;
+    while (G < 16 && (long long)n > 24ll * G * nU) G <<= 1;
+    const int j = lane & (G - 1), gbase = lane - j, g = lane / G, ngrp = WAVE / G;
+    int bits = 32 - __clz(nU);
+    int shift = 58 - bits; if (shift > 48) shift = 48;
+    const double fxscale = (double)(1ull << shift);
+    const double pne = 1.0 - 3e-5;                                     // pcr_no_error, :20
+
+    uint32_t accv[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) accv[k] = 0;
+    uint32_t conc_ref = 0, disc_ref = 0;
+    lmask err_m = 0, redo_m = 0;
+    uint32_t n_frag_seen = 0, n_bc = 0;
+    long long pi_acc[4] = {0, 0, 0, 0};
+    int mt_acc[4] = {0, 0, 0, 0}, st_acc[4] = {0, 0, 0, 0};
+    int c3 = 0, c5 = 0, c7 = 0, c10 = 0, ufrag = 0;
+    uint32_t touch_lo = 0, touch_hi = 0;
+
+    // One barcode: every lane of the group takes one aligned quad of 4 reads per step (one 16-byte load
+    // per plane, next step prefetched in registers); reads outside [rb, re) belong to a neighbouring barcode
+    // and are masked.  fn(present, allele, pidx) is called for every read slot; only the read closing a
+    // fragment passes present = true.
+    const uint4* meta4 = (const uint4*)meta;
+    const uint4* umi4 = (const uint4*)umi;
+    const uint4* frag4 = (const uint4*)frag;
+    const uint4* dist4 = (const uint4*)dist;
+    auto walk = [&](uint32_t u_expect, uint32_t rb, uint32_t re, bool tally, auto&& fn) -> bool {
+        const uint32_t q0 = rb >> 2, q1 = (re + 3u) >> 2;
+        const uint4 none4 = make_uint4(PK_NONE, PK_NONE, PK_NONE, PK_NONE), zero4 = make_uint4(0, 0, 0, 0);
+        uint4 cm = zero4, cf = none4, cd = zero4, cu = zero4, nm, nf4, nd, nu;
+        {
+            const uint32_t q = q0 + j;
+            if (q < q1) { cm = meta4[q]; cf = frag4[q]; cd = dist4[q]; cu = umi4[q]; }
+        }
+        uint32_t carry = PK_NONE;
+        bool any_inc = false;
+        for (uint32_t qs = q0; qs < q1; qs += G) {
+            const uint32_t q = qs + j;
+            {
+                const uint32_t qn = q + G;
+                nm = zero4; nf4 = none4; nd = zero4; nu = zero4;
+                if (qn < q1) { nm = meta4[qn]; nf4 = frag4[qn]; nd = dist4[qn]; nu = umi4[qn]; }
+            }
+            const uint32_t ms[4] = {cm.x, cm.y, cm.z, cm.w}, fs[4] = {cf.x, cf.y, cf.z, cf.w};
+            const uint32_t ds[4] = {cd.x, cd.y, cd.z, cd.w}, us[4] = {cu.x, cu.y, cu.z, cu.w};
+            uint32_t pk[4], slot[4];
+            lmask m_okk[4], m_inck[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t r = 4u * q + k;
+                const uint32_t mw = ms[k], f = fs[k], dw = ds[k];
+                const uint32_t a = mw & 0xffu, kind = (mw >> 19) & 3u;
+                const lmask m_valid = BAL(r >= rb) & BAL(r < re);
+                const lmask m_ok = m_valid & BAL(f < (uint32_t)nF) & BAL(a < (uint32_t)nA) & BAL(us[k] == u_expect);
+                err_m |= m_valid & ~m_ok;
+                const lmask m_base = BAL(kind == SMC_KIND_BASE), m_gap = BAL(kind == SMC_KIND_GAP);
+                const lmask m_qok = BAL((int)((mw >> 8) & 0xffu) >= P.min_bq);
+                const lmask m_inc = m_ok & (m_qok | m_gap) & BAL((int)(mw >> 24) >= P.min_mq) & BAL((mw & 0x40000u) != 0u);
+                m_okk[k] = m_ok; m_inck[k] = m_inc;
+                if (tally) {
+                    const lmask m_r2 = BAL((mw & 0x10000u) != 0u), m_rev = BAL((mw & 0x20000u) != 0u);
+                    const lmask m_ref = m_ok & BAL(a == refa);
+                    const lmask m_ib = m_inc & m_base;
+                    const lmask m_r1i = m_ib & ~m_r2, m_r2i = m_ib & m_r2;
+                    const lmask m_le20 = BAL((dw & 0xffffu) <= 20u), m_prle = BAL((int)(dw >> 16) <= P.primer_dist);
+                    const lmask e_fwd = ~m_gap & ~m_rev, e_rev = ~m_gap & m_rev, e_lowq = m_base & ~m_qok;
+                    ADDM(accv[SMC_T_CNT], m_ref);
+                    ADDM(accv[SMC_T_FWD], m_ref & e_fwd);
+                    ADDM(accv[SMC_T_REV], m_ref & e_rev);
+                    ADDM(accv[SMC_T_LOWQ], m_ref & e_lowq);
+                    ADDM(accv[SMC_T_R1N], m_ref & m_r1i);
+                    ADDM(accv[SMC_T_R1LE], m_ref & m_r1i & m_le20);
+                    ADDM(accv[SMC_T_R2N], m_ref & m_r2i);
+                    ADDM(accv[SMC_T_R2BCLE], m_ref & m_r2i & m_le20);
+                    ADDM(accv[SMC_T_R2PRLE], m_ref & m_r2i & m_prle);
+                    const lmask nr = m_ok & ~m_ref;
+                    if (nr) {                                           // stray alleles: predicated LDS adds
+                        uint32_t* t = tal + a * SMC_NT;
+                        if (LANES(nr)) atomicAdd(&t[SMC_T_CNT], 1u);
+                        if (LANES(nr & e_fwd)) atomicAdd(&t[SMC_T_FWD], 1u);
+                        if (LANES(nr & e_rev)) atomicAdd(&t[SMC_T_REV], 1u);
+                        if (LANES(nr & e_lowq)) atomicAdd(&t[SMC_T_LOWQ], 1u);
+                        if (LANES(nr & m_r1i)) atomicAdd(&t[SMC_T_R1N], 1u);
+                        if (LANES(nr & m_r1i & m_le20)) atomicAdd(&t[SMC_T_R1LE], 1u);
+                        if (LANES(nr & m_r2i)) atomicAdd(&t[SMC_T_R2N], 1u);
+                        if (LANES(nr & m_r2i & m_le20)) atomicAdd(&t[SMC_T_R2BCLE], 1u);
+                        if (LANES(nr & m_r2i & m_prle)) atomicAdd(&t[SMC_T_R2PRLE], 1u);
+                    }
+                }
+                const bool inc = LANES(m_inc);
+                uint32_t qv = LANES(m_gap) ? (uint32_t)P.min_bq : ((mw >> 8) & 0xffu);             // :418
+                qv = qv < PIDX_UNPAIRED ? qv : PIDX_UNPAIRED - 1u;
+                slot[k] = LANES(m_ok) ? f : PK_NONE;
+                pk[k] = LANES(m_ok) ? ((f << 14) | (a << 8) | (qv << 1) | (uint32_t)inc) : PK_NONE;
+                any_inc |= inc;
+            }
+            // neighbours across lanes: the previous lane's last read, the next lane's first read
+            uint32_t prev0 = (uint32_t)__shfl_up((int)pk[3], 1, G);
+            if (j == 0) prev0 = carry;
+            uint32_t next3 = (uint32_t)__shfl_down((int)slot[0], 1, G);
+            {
+                // first read of the next step (lane 0 of the group), if it still belongs to this barcode
+                const uint32_t nx = (uint32_t)__shfl((int)nf4.x, gbase);
+                const uint32_t look = (4u * (qs + G) < re) ? nx : PK_NONE;
+                if (j == G - 1) next3 = look;
+            }
+            carry = (uint32_t)__shfl((int)pk[3], gbase + G - 1);
+            // ---- mate merge by neighbour compare (smCounter.py:468-479)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t prev = k ? pk[k - 1] : prev0;
+                const uint32_t next_slot = k < 3 ? slot[k + 1] : next3;
+                const uint32_t cur = pk[k], sl = slot[k];
+                const uint32_t a = (cur >> 8) & 63u, qv = (cur >> 1) & 127u;
+                const bool inc = (cur & 1u) != 0u && cur != PK_NONE;
+                const bool has_prev = prev != PK_NONE;
+                const uint32_t pslot = prev >> 14, pa = (prev >> 8) & 63u, pq = (prev >> 1) & 127u;
+                const bool pinc = has_prev && (prev & 1u);
+                const bool is_first = !(has_prev && pslot == sl), is_last = next_slot != sl;
+                const lmask m_v = m_okk[k];
+                redo_m |= m_v & BAL(!is_first) & BAL(!is_last);          // a run of >= 3 reads
+                err_m |= m_v & BAL(has_prev && pslot > sl);              // not sorted
+                const bool both = !is_first && pinc && inc;
+                const bool same = a == pa || a == (uint32_t)N_ID;
+                const bool present = is_first ? inc : (both ? same : (pinc || inc));
+                const uint32_t fa = (!is_first && pinc) ? pa : a;
+                const uint32_t fq = both ? (pq < qv ? pq : qv) : ((!is_first && pinc) ? pq : qv);
+                const bool paired = both && same;
+                const lmask m_close = m_v & BAL(is_last);
+                if (tally) {
+                    ADDM(n_frag_seen, m_close);          // per lane (groups diverge); summed at the end
+                    const lmask m_conc = m_close & BAL(both && a == pa), m_disc = m_close & BAL(both && !same);
+                    const lmask c_ref = m_conc & BAL(a == refa), d_ref = m_disc & BAL(a == refa);
+                    ADDM(conc_ref, c_ref);
+                    ADDM(disc_ref, d_ref);
+                    const lmask rare = (m_conc & ~c_ref) | (m_disc & ~d_ref);
+                    if (rare) {
+                        if (LANES(m_conc & ~c_ref)) atomicAdd(&tal[a * SMC_NT + SMC_T_CONCORD], 1u);
+                        if (LANES(m_disc & ~d_ref)) atomicAdd(&tal[a * SMC_NT + SMC_T_DISCORD], 1u);
+                    }
+                }
+                fn(LANES(m_close) && present, fa, paired ? fq : PIDX_UNPAIRED);
+            }
+            cm = nm; cf = nf4; cd = nd; cu = nu;
+        }
+        return any_inc;
+    };
+
+    for (int ub0 = 0; ub0 < nU; ub0 += UB) {
+        const int nb = nU - ub0 < UB ? nU - ub0 : UB;
+        // ---- walk phase
+        for (int t = g; t < nb; t += ngrp) {
+            const int u = ub0 + t;
+            const uint32_t rb = ustart[u], re = ustart[u + 1];
+            if (!(rb < re && re <= (uint32_t)n) || (u == 0 && rb != 0)) { err_m |= 1; continue; }
+            int nf = 0, cnt_ref = 0;
+            unsigned long long mk = 0;
+            double rp = 1.0, pr = 1.0;
+            const bool any_inc = walk((uint32_t)u, rb, re, true, [&](bool present, uint32_t fa, uint32_t pidx) {
+                const double p = lut[pidx & (LUT_N - 1)], q1 = 1.0 - p;
+                const bool isref = fa == refa;
+                nf += present;
+                cnt_ref += present && isref;
+                mk |= present ? (1ull << fa) : 0ull;
+                rp *= present ? q1 : 1.0;
+                pr *= present ? (isref ? q1 : p) : 1.0;
+            });
+            nf = wave_reduce_add(nf, G);
+            cnt_ref = wave_reduce_add(cnt_ref, G);
+            const uint32_t mlo = wave_reduce_or((uint32_t)mk, G), mhi = wave_reduce_or((uint32_t)(mk >> 32), G);
+            const uint32_t inb = wave_reduce_or((uint32_t)any_inc, G);
+            rp = wave_reduce_mul(rp, G);
+            pr = wave_reduce_mul(pr, G);
+            if (j == 0) {
+                URec& R = urec[t];
+                R.rightP = rp; R.prod_ref = pr; R.mlo = mlo; R.mhi = mhi; R.nf = nf; R.cnt_ref = cnt_ref;
+                R.rb = rb; R.re = re; R.in_bc = inb;
+            }
+        }
+        __syncthreads();
+        // ---- math phase: one lane per barcode of the batch (calProb :26-98, PI / consensus :506-532)
+        bool complex = false;
+        {
+            URec R;
+            R.in_bc = 0; R.nf = 0; R.mlo = R.mhi = 0; R.cnt_ref = 0; R.rightP = R.prod_ref = 1.0;
+            if (lane < nb) R = urec[lane];
+            const lmask m_bc = BAL(lane < nb && R.in_bc != 0u);
+            // down-sampling stand-in (non-parity, :496-498): keep the ds lowest barcode ids of bcDict
+            const int rank = (int)n_bc + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_bc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_bc, 0u));
+            n_bc += (uint32_t)__popcll(m_bc);
+            const bool kept = LANES(m_bc) && rank < P.ds;
+            if (lane < nb && R.in_bc) urec[lane].in_bc = kept ? 1u : 0u;
+            if (kept) {
+                const int nf = R.nf;
+                const unsigned long long mask = ((unsigned long long)R.mhi << 32) | R.mlo;
+                ufrag += nf; c3 += nf >= 3; c5 += nf >= 5; c7 += nf >= 7; c10 += nf >= 10;
+                if (nf <= P.mt_drop) {                                 // :28-32 -> all four posteriors 0
+                    touch_lo |= 0xFu;
+                    if (nf == 1) {                                     // :521-523
+                        const int a = __ffsll((long long)mask) - 1;
+                        if (a < 4) { for (int k = 0; k < 4; ++k) if (k == a) mt_acc[k]++; } else atomicAdd(&mtc[a], 1u);
+                    }
+                } else if (!(refa < 64u && mask == (1ull << refa))) {
+                    complex = true;
+                } else {
+                    // one existing allele (the reference), three padded keys (:49-54): nk = 4
+                    const unsigned long long padmask = refa < 4 ? (0xFull & ~(1ull << refa)) : 0x7ull;
+                    const double denom = nf + 2.0;                     // :80
+                    const double pcr_self = pcr_of(nf, denom), pcr_zero = pcr_of(0, denom);
+                    const double tmp0 = pne * R.prod_ref + R.rightP * pcr_zero;    // :86
+                    const double padOut = R.rightP * pcr_self;         // :88-91
+                    double sumP = tmp0;
+                    sumP += padOut; sumP += padOut; sumP += padOut;
+                    const double post0 = sumP <= 0 ? 0.0 : tmp0 / sumP, postp = sumP <= 0 ? 0.0 : padOut / sumP;
+                    const double x0 = 1.0 - post0;
+                    const double pred0 = x0 > 0.0 ? -log10(x0) : 16.0; // :508-510
+                    double predpad;
+                    if (postp < 1e-6) predpad = postp * (1.0 + postp * (0.5 + postp * (1.0 / 3.0))) * 0.43429448190325182765;
+                    else { const double xp = 1.0 - postp; predpad = xp > 0.0 ? -log10(xp) : 16.0; }
+                    const long long fx0 = (long long)(pred0 * fxscale + 0.5), fxp = (long long)(predpad * fxscale + 0.5);
+                    if (refa >= 4) atomicAdd(&pifx[refa], (unsigned long long)fx0);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        if (a == (int)refa) pi_acc[a] += fx0;
+                        else if ((padmask >> a) & 1ull) pi_acc[a] += fxp;
+                    }
+                    const unsigned long long uq = mask | padmask;
+                    touch_lo |= (uint32_t)uq; touch_hi |= (uint32_t)(uq >> 32);
+                    if (pred0 > predpad) {                             // unique maximum (:514-519)
+                        const bool str = pred0 > P.smt;
+                        if (refa < 4) {
+#pragma unroll
+                            for (int a = 0; a < 4; ++a) if (a == (int)refa) { mt_acc[a]++; st_acc[a] += str; }
+                        } else { atomicAdd(&mtc[refa], 1u); if (str) atomicAdd(&strong[refa], 1u); }
+                    } else if (nf == 1) {                              // :521-523
+                        if (refa < 4) {
+#pragma unroll
+                            for (int a = 0; a < 4; ++a) if (a == (int)refa) mt_acc[a]++;
+                        } else atomicAdd(&mtc[refa], 1u);
+                    }
+                }
+            }
+        }
+        // ---- barcodes with another allele: queue, then re-walk for per-allele counts and products
+        const lmask m_cx = BAL(complex);
+        const int n_complex = __popcll(m_cx);
+        if (complex) clist[__builtin_amdgcn_mbcnt_hi((uint32_t)(m_cx >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_cx, 0u))] = (uint32_t)lane;
+        __syncthreads();
+        for (int w = g; w < n_complex; w += ngrp) {
+            const URec R = urec[clist[w]];
+            const int nf = R.nf;
+            const unsigned long long mask = ((unsigned long long)R.mhi << 32) | R.mlo;
+            const int n_exist = __popcll(mask);
+            if (n_exist > 4) { redo_m |= 1; continue; }              // rare: the table kernel handles it
+            int npad = 4 - n_exist;
+            unsigned long long padmask = 0;
+            for (int a = 0, k = 0; a < 4 && k < npad; ++a)
+                if (!((mask >> a) & 1ull)) { padmask |= 1ull << a; ++k; }   // :49-54, atgc order
+            const int nk = n_exist + npad;
+            const double denom = nf + 0.5 * nk;                        // :80
+            int ida[4] = {0, 0, 0, 0}, cnta[4] = {0, 0, 0, 0};
+            double proda[4] = {1.0, 1.0, 1.0, 1.0};
+            {
+                unsigned long long mm = mask;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < n_exist) { ida[k] = __ffsll((long long)mm) - 1; mm &= mm - 1; }
+            }
+            (void)walk((uint32_t)(ub0 + (int)clist[w]), R.rb, R.re, false, [&](bool present, uint32_t fa, uint32_t pidx) {     // :62-77
+                const double p = lut[pidx & (LUT_N - 1)];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < n_exist) {
+                        const bool sm = (int)fa == ida[k];
+                        cnta[k] += present && sm;
+                        proda[k] *= present ? (sm ? 1.0 - p : p) : 1.0;
+                    }
+            });
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                cnta[k] = wave_reduce_add(cnta[k], G);
+                proda[k] = wave_reduce_mul(proda[k], G);
+            }
+            int max1 = -1, max2 = -1, arg1 = -1, arg2 = -1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < n_exist) {
+                    if (cnta[k] > max1) { max2 = max1; arg2 = arg1; max1 = cnta[k]; arg1 = k; }
+                    else if (cnta[k] > max2) { max2 = cnta[k]; arg2 = k; }
+                }
+            double prodpcr = 1.0, tmpv[4] = {0, 0, 0, 0}, pcrv[4] = {0, 0, 0, 0}, sumP = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < n_exist) { pcrv[k] = pcr_of(cnta[k], denom); prodpcr *= pcrv[k]; }
+            const double pcr0 = n_exist == 1 ? pcr_of(0, denom) : 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < n_exist) {
+                    const int oi = (k == arg1) ? arg2 : arg1;
+                    double po = pcr0;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) po = (m == oi) ? pcrv[m] : po;
+                    tmpv[k] = pne * proda[k] + R.rightP * po;                       // :86
+                    sumP += tmpv[k];
+                }
+            const double padOut = R.rightP * prodpcr;                  // :88-91
+            for (int k = 0; k < npad; ++k) sumP += padOut;
+            double predv[4] = {0, 0, 0, 0}, mx = -1.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < n_exist) {
+                    const double post = sumP <= 0 ? 0.0 : tmpv[k] / sumP;
+                    const double x = 1.0 - post;
+                    predv[k] = x > 0.0 ? -log10(x) : 16.0;
+                    if (predv[k] > mx) mx = predv[k];
+                }
+            double predpad = 0.0;
+            if (npad) {
+                const double post = sumP <= 0 ? 0.0 : padOut / sumP;
+                if (post < 1e-6) predpad = post * (1.0 + post * (0.5 + post * (1.0 / 3.0))) * 0.43429448190325182765;
+                else { const double x = 1.0 - post; predpad = x > 0.0 ? -log10(x) : 16.0; }
+                if (predpad > mx) mx = predpad;
+            }
+            if (j == 0) {
+                int n_max = 0, cons = -1;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < n_exist) {
+                        const int a = ida[k];
+                        const long long fx = (long long)(predv[k] * fxscale + 0.5);
+                        if (a < 4) { for (int m = 0; m < 4; ++m) if (m == a) pi_acc[m] += fx; }
+                        else atomicAdd(&pifx[a], (unsigned long long)fx);
+                        if (predv[k] == mx) { ++n_max; cons = a; }                 // :514
+                    }
+                if (npad) {
+                    const long long fx = (long long)(predpad * fxscale + 0.5);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+                        if ((padmask >> a) & 1ull) {
+                            pi_acc[a] += fx;
+                            if (predpad == mx) { ++n_max; cons = a; }
+                        }
+                }
+                const unsigned long long uq = mask | padmask;
+                touch_lo |= (uint32_t)uq; touch_hi |= (uint32_t)(uq >> 32);
+                if (n_max == 1) {                                                    // :515-519
+                    const bool str = mx > P.smt;
+                    if (cons < 4) { for (int m = 0; m < 4; ++m) if (m == cons) { mt_acc[m]++; st_acc[m] += str; } }
+                    else { atomicAdd(&mtc[cons], 1u); if (str) atomicAdd(&strong[cons], 1u); }
+                } else if (nf == 1) {                                                // :521-523
+                    const int a = ida[0];
+                    if (a < 4) { for (int m = 0; m < 4; ++m) if (m == a) mt_acc[m]++; } else atomicAdd(&mtc[a], 1u);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- anything this kernel does not handle exactly goes to the table kernel
+    if (BAL(redo_m != 0)) {
+        if (lane == 0) redo_flag[li] = 1;
+        return;
+    }
+    // ---- fold lane accumulators into the LDS image the row is built from
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const uint32_t v = (uint32_t)wave_reduce_add((int)accv[k], WAVE);
+        if (lane == 0 && v && refa < (uint32_t)nA) tal[refa * SMC_NT + k] += v;
+    }
+    {
+        const uint32_t c = (uint32_t)wave_reduce_add((int)conc_ref, WAVE), d = (uint32_t)wave_reduce_add((int)disc_ref, WAVE);
+        if (lane == 0 && refa < (uint32_t)nA) { tal[refa * SMC_NT + SMC_T_CONCORD] += c; tal[refa * SMC_NT + SMC_T_DISCORD] += d; }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const long long p = wave_reduce_add64(pi_acc[a], WAVE);
+        const int m = wave_reduce_add(mt_acc[a], WAVE), s = wave_reduce_add(st_acc[a], WAVE);
+        if (lane == 0) { pifx[a] += (unsigned long long)p; mtc[a] += (uint32_t)m; strong[a] += (uint32_t)s; }
+    }
+    c3 = wave_reduce_add(c3, WAVE); c5 = wave_reduce_add(c5, WAVE);
+    c7 = wave_reduce_add(c7, WAVE); c10 = wave_reduce_add(c10, WAVE);
+    ufrag = wave_reduce_add(ufrag, WAVE);
+    touch_lo = wave_reduce_or(touch_lo, WAVE); touch_hi = wave_reduce_or(touch_hi, WAVE);
+    const bool bad = BAL(err_m != 0) != 0 || (uint32_t)wave_reduce_add((int)n_frag_seen, WAVE) != (uint32_t)nF;
+    const int used = (int)n_bc < P.ds ? (int)n_bc : P.ds;             // smCounter.py:489
+    if (lane == 0) {
+        H->misc[M_MT3] = c3; H->misc[M_MT5] = c5; H->misc[M_MT7] = c7; H->misc[M_MT10] = c10;
+        H->misc[M_USEDFRAG] = ufrag; H->misc[M_TOUCH_LO] = touch_lo; H->misc[M_TOUCH_HI] = touch_hi;
+        H->misc[M_ALLMT] = nU;
+        smc_row* R = rowst;
+        if (bad || used == 0) {
+            R->status = bad ? SMC_ST_BAD_INPUT : SMC_ST_ZERO_COVERAGE;    // :492-494
+            R->cvg = n; R->all_mt = nU; R->all_frag = nF;
+            R->max_allele = R->second_allele = -1;
+            for (int k = 0; k < 4; ++k) R->dp[k] = tal[k * SMC_NT + SMC_T_CNT];
+            for (int c = 0; c < 2; ++c) {
+                R->cand[c].allele = -1;
+                R->cand[c].p_sb = R->cand[c].p_r1 = R->cand[c].p_r2 = R->cand[c].p_pr = NAN;
+            }
+        } else {
+            finish_row(R, L, li, n, nF, used, (int)n_bc > P.ds, fxscale, H->misc, tal, pifx, mtc, strong, flt_list);
+        }
+    }
+    __syncthreads();
+    const uint32_t* src = (const uint32_t*)rowst;
+    uint32_t* dst = (uint32_t*)(rows + li);
+    for (int i = lane; i < (int)(sizeof(smc_row) / 4); i += WAVE) dst[i] = src[i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1097,6 +1582,13 @@ struct smc_plan {
     int64_t n_loci;
     smc_locus* d_loci = nullptr;
     uint32_t* d_flt_list = nullptr;   // [0] = count, then locus indices queued for k_filter_loci
+    // sorted-stream path: every locus in one launch (heaviest first), hand-over flags for the table kernel
+    int use_sorted = 1;
+    int* d_all_order = nullptr;
+    smc_locus* d_all_loci = nullptr;
+    uint8_t* d_redo = nullptr;
+    int a_cap_all = 8;
+    int64_t total_reads = 0;
     std::vector<Bin> bins;
     // optional HIP-event timing of the dominant k_call_loci launch (the bin with most reads)
     int timing = 0, dom_bin = -1;
@@ -1114,7 +1606,8 @@ static hipError_t launch_bin(const Bin& b, const KParams& kp, const smc_plan* p,
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)b.order.size()), dim3(BLOCK), b.lds_bytes, st, kp, b.d_loci, b.d_order, b.a_cap,
-                       meta, umi, frag, dist, p->ctx->lut, rows, b.d_scratch, b.d_scratch_off, p->d_flt_list);
+                       meta, umi, frag, dist, p->ctx->lut, rows, b.d_scratch, b.d_scratch_off, p->d_flt_list,
+                       p->use_sorted ? p->d_redo : (const uint8_t*)nullptr);
     return hipGetLastError();
 }
 
@@ -1164,6 +1657,9 @@ void smc_plan_destroy(smc_plan* p) {
     (void)hipSetDevice(p->ctx->device);
     (void)hipFree(p->d_loci);
     (void)hipFree(p->d_flt_list);
+    (void)hipFree(p->d_all_order);
+    (void)hipFree(p->d_all_loci);
+    (void)hipFree(p->d_redo);
     for (auto e : p->ev0) (void)hipEventDestroy(e);
     for (auto e : p->ev1) (void)hipEventDestroy(e);
     for (auto& b : p->bins) {
@@ -1202,6 +1698,29 @@ int smc_plan_create(smc_ctx* ctx, const smc_locus* loci, int64_t n_loci, smc_pla
         if (a_cap > b.a_cap) b.a_cap = a_cap;
     }
     HIPCHK(hipMalloc(&p->d_flt_list, sizeof(uint32_t) * ((size_t)n_loci + 4)));
+    {
+        // SMC_KERNEL=sorted runs the sorted-stream kernel first and the table kernel only on the loci it
+        // hands over; the default is the table kernel alone, which is faster on every shape measured
+        // ("Explored: sorted-stream kernel")
+        const char* env = getenv("SMC_KERNEL");
+        p->use_sorted = (env && strcmp(env, "sorted") == 0);
+        std::vector<int> all((size_t)n_loci);
+        for (int64_t l = 0; l < n_loci; ++l) { all[(size_t)l] = (int)l; p->total_reads += loci[l].n_reads; }
+        std::stable_sort(all.begin(), all.end(), [&](int x, int y) { return loci[x].n_reads > loci[y].n_reads; });
+        std::vector<smc_locus> perm((size_t)n_loci);
+        for (int64_t k = 0; k < n_loci; ++k) {
+            perm[(size_t)k] = loci[all[(size_t)k]];
+            const int ac = (perm[(size_t)k].n_alleles + 7) & ~7;
+            if (ac > p->a_cap_all) p->a_cap_all = ac;
+        }
+        HIPCHK(hipMalloc(&p->d_all_order, sizeof(int) * (size_t)(n_loci + 1)));
+        HIPCHK(hipMalloc(&p->d_all_loci, sizeof(smc_locus) * (size_t)(n_loci + 1)));
+        HIPCHK(hipMalloc(&p->d_redo, (size_t)n_loci + 16));
+        if (n_loci) {
+            HIPCHK(hipMemcpy(p->d_all_order, all.data(), sizeof(int) * (size_t)n_loci, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(p->d_all_loci, perm.data(), sizeof(smc_locus) * (size_t)n_loci, hipMemcpyHostToDevice));
+        }
+    }
     if (n_loci) {
         HIPCHK(hipMalloc(&p->d_loci, sizeof(smc_locus) * (size_t)n_loci));
         HIPCHK(hipMemcpy(p->d_loci, loci, sizeof(smc_locus) * (size_t)n_loci, hipMemcpyHostToDevice));
@@ -1267,8 +1786,8 @@ int smc_plan_kernel_ms(smc_plan* p, float* avg_ms, int32_t* n_samples, int64_t* 
     }
     *avg_ms = (float)(tot / ns);
     if (n_samples) *n_samples = (int32_t)ns;
-    if (n_loci) *n_loci = p->dom_loci;
-    if (n_reads) *n_reads = p->dom_reads;
+    if (n_loci) *n_loci = p->use_sorted ? p->n_loci : p->dom_loci;
+    if (n_reads) *n_reads = p->use_sorted ? p->total_reads : p->dom_reads;
     return SMC_OK;
 }
 
@@ -1293,9 +1812,21 @@ int smc_plan_run(smc_plan* p, const smc_params* prm, const uint32_t* meta, const
     hipStream_t st = (hipStream_t)stream;
     KParams kp{prm->min_bq, prm->min_mq, prm->mt_drop, prm->primer_dist, prm->ds, prm->smt};
     HIPCHK(hipMemsetAsync(p->d_flt_list, 0, 16, st));
+    if (p->use_sorted) {
+        HIPCHK(hipMemsetAsync(p->d_redo, 0, (size_t)p->n_loci, st));
+        const size_t lds = (sizeof(Hdr) + (size_t)p->a_cap_all * 64 + sizeof(smc_row) + 128 * 8 + UB * sizeof(URec) + UB * 4 + 255) & ~(size_t)255;
+        const bool timed = p->timing > 0;
+        const size_t slot = timed ? (size_t)(p->n_timed % p->timing) : 0;
+        if (timed) HIPCHK(hipEventRecord(p->ev0[slot], st));
+        hipLaunchKernelGGL(k_call_sorted, dim3((unsigned)p->n_loci), dim3(WAVE), lds, st, kp, p->d_all_loci, p->d_all_order,
+                           p->a_cap_all, meta, umi, frag, dist, umi_start, p->ctx->lut, rows, p->d_flt_list, p->d_redo);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(SMC_E_HIP, std::string("k_call_sorted launch: ") + hipGetErrorString(e));
+        if (timed) { HIPCHK(hipEventRecord(p->ev1[slot], st)); p->n_timed++; }
+    }
     for (size_t bi = 0; bi < p->bins.size(); ++bi) {
         const Bin& b = p->bins[bi];
-        const bool timed = p->timing > 0 && (int)bi == p->dom_bin;
+        const bool timed = !p->use_sorted && p->timing > 0 && (int)bi == p->dom_bin;
         const size_t slot = timed ? (size_t)(p->n_timed % p->timing) : 0;
         if (timed) HIPCHK(hipEventRecord(p->ev0[slot], st));
         hipError_t e = hipSuccess;

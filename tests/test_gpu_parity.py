@@ -134,3 +134,25 @@ def test_full_size_properties(engine0):
     hi = synth.generate_native(cfg, half, cfg.n_loci, P)
     both = np.concatenate([engine0.call_batch_host(lo, P), engine0.call_batch_host(hi, P)])
     assert both.tobytes() == got.tobytes()
+
+
+def test_sorted_stream_kernel_variant(monkeypatch):
+    """SMC_KERNEL=sorted: the one-wave-per-locus stream kernel (+ hand-over of loci with re-created
+    fragments to the table kernel) must produce the same rows as the default path."""
+    from smcounter_amd import engine
+    monkeypatch.setenv("SMC_KERNEL", "sorted")
+    eng = engine.Engine(0)
+    try:
+        for path in golden_files()[:4]:
+            pb, db, P, refp, expected = load_golden(path)
+            got = eng.call_batch_host(db, P)
+            want, fragile = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE, return_fragile=True)
+            assert abi.compare_rows(got, want, PI_TOL, P_TOL, fragile) == []
+        cfg = synth.CONFIGS["C3"]
+        P = synth.params_for(cfg)
+        db = synth.generate_native(cfg, 0, 600, P)
+        got = eng.call_batch_host(db, P)
+        want, fragile = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE, return_fragile=True)
+        assert abi.compare_rows(got, want, PI_TOL, P_TOL, fragile) == []
+    finally:
+        eng.close()
