@@ -9,7 +9,7 @@ cfg = synth.CONFIGS[sys.argv[1]]; n = int(sys.argv[2]); libs = sys.argv[3:]
 P = synth.params_for(cfg)
 db = synth.generate_native(cfg, 0, n)
 dev = torch.device("cuda", 0)
-planes = [torch.from_numpy(np.ascontiguousarray(x).view(np.int32)).to(dev) for x in (db.meta, db.umi, db.frag, db.dist)]
+planes = [torch.from_numpy(np.ascontiguousarray(x).view(np.int32)).to(dev) for x in (db.meta, db.umi, db.frag, db.dist, db.umi_start)]
 rows = torch.empty(n * abi.ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev)
 vp = ctypes.c_void_p
 H = []
@@ -17,7 +17,7 @@ for path in libs:
     L = ctypes.CDLL(os.path.join(ROOT, "smcounter_amd", path))
     L.smc_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
     L.smc_plan_create.argtypes = [vp, vp, ctypes.c_int64, ctypes.POINTER(vp)]
-    L.smc_plan_run.argtypes = [vp, ctypes.POINTER(abi.SmcParams), vp, vp, vp, vp, vp, vp]
+    L.smc_plan_run.argtypes = [vp, ctypes.POINTER(abi.SmcParams), vp, vp, vp, vp, vp, vp, vp]
     L.smc_last_error.restype = ctypes.c_char_p
     ctx, plan = vp(), vp()
     assert L.smc_create(0, ctypes.byref(ctx)) == 0, L.smc_last_error()
@@ -28,7 +28,7 @@ cp = abi.c_params(P)
 st = torch.cuda.current_stream()
 def run(L, plan):
     rc = L.smc_plan_run(plan, ctypes.byref(cp), planes[0].data_ptr(), planes[1].data_ptr(), planes[2].data_ptr(),
-                        planes[3].data_ptr(), rows.data_ptr(), vp(st.cuda_stream))
+                        planes[3].data_ptr(), planes[4].data_ptr(), rows.data_ptr(), vp(st.cuda_stream))
     assert rc == 0, L.smc_last_error()
 res = {p: [] for p, _, _ in H}
 ref = None
