@@ -49,6 +49,21 @@ def build_synth(force: bool = False) -> str:
     return SYNTH_LIB
 
 
+BAM_SRC = os.path.join(HERE, "csrc", "smc_bam.cpp")
+BAM_LIB = os.path.join(HERE, "libsmc_bam.so")
+
+
+def build_bam(force: bool = False) -> str:
+    """Native BGZF/BAM pileup decoder (plain g++ + zlib)."""
+    hdr = os.path.join(ROOT, "include", "smcounter_hip.h")
+    if force or not os.path.exists(BAM_LIB) or \
+            max(os.path.getmtime(BAM_SRC), os.path.getmtime(hdr)) > os.path.getmtime(BAM_LIB):
+        subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-pthread",
+                               "-I" + os.path.join(ROOT, "include"), "-o", BAM_LIB, BAM_SRC, "-lz"])
+    return BAM_LIB
+
+
 if __name__ == "__main__":
     print(build_hip(force=True))
     print(build_synth(force=True))
+    print(build_bam(force=True))

@@ -73,14 +73,17 @@ def main(args) -> int:
                       mismatchThr=args.mismatchThr, mtDrop=args.mtDrop, maxMT=args.maxMT, primerDist=args.primerDist)
     loc_list = bedops.expand_loci(args.bedTarget)
     ref = fasta.FastaFile(args.refGenome)
-    bam = bamio.BamFile(args.bamFile)
     from .engine import Engine
     eng = Engine(args.device)
     output = []
-    for first, pb in bamio.iter_pileup_batches(bam, ref, loc_list, max_reads=args.batchReads):
+    if os.environ.get("SMC_BAM_DECODER", "native") == "python":       # readable decoder, same batches
+        bam = bamio.BamFile(args.bamFile)
+        batches = bamio.iter_pileup_batches(bam, ref, loc_list, max_reads=args.batchReads)
+    else:
+        batches = bamio.iter_device_batches_native(args.bamFile, ref, loc_list, params, max_reads=args.batchReads)
+    for first, pb in batches:
         output.extend(vc.vc_batch(pb, params, ref, eng=eng))
     eng.close()
-    bam.close()
     vc.raise_on_exception(output, loc_list)
 
     print("begin variant filtering and output")

@@ -1,0 +1,572 @@
+// smc_bam.cpp - native BGZF/BAM reader and single-position pileup.
+//
+// Same semantics as smcounter_amd/bamio.py (which stays as the readable reference and the fallback):
+// what the reference takes from `samfile.pileup(region, truncate=True, max_depth=1000000,
+// stepper='nofilter')` at smCounter.py:316-448 - every mapped alignment covering the position in file
+// order, no filtering; query_position incl. soft clips; is_del inside D/N; indel = the I (+) / D (-) that
+// starts right after the position (samtools 0.1.19 resolve_cigar).  Barcode / read ids are made dense per
+// locus in order of first appearance (smCounter.py:463-464), alleles are ids into a per-locus key table.
+// Keys of deletion-start alleles need the reference sequence; they are emitted as "D<len>|<site>" and
+// completed by the Python caller from the FASTA (bamio.NativeBam).
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+#include "smcounter_hip.h"   // smc_locus: the descriptor smc_bam_planes fills
+
+#include <atomic>
+#include <chrono>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+struct Aln {
+    int32_t pos, end;
+    uint16_t flag;
+    uint8_t mapq, has_nm;
+    uint32_t nm, l_seq;
+    std::string qname, seq;
+    std::vector<uint8_t> qual;
+    std::vector<uint32_t> cigar;   // len << 4 | op
+    int32_t bc_gid, pair_gid;      // run-wide ids of the barcode and of (barcode, read id)
+    uint32_t n_ind, qalen, left_sp;
+    uint8_t oflag;
+};
+
+struct Bam {
+    FILE* fh = nullptr;
+    std::string err;
+    std::vector<std::string> ref_names;
+    std::vector<int32_t> ref_lens;
+    std::vector<std::vector<uint64_t>> lin;   // BAI linear index per reference
+    uint64_t first_record = 0;
+    // BGZF state
+    std::vector<uint8_t> buf;
+    size_t off = 0;
+    uint64_t block_start = 0, next_block = 0;
+    // last pileup result
+    std::vector<uint32_t> umi, frag, nm, n_indel, left_sp, qlen, qalen;
+    std::vector<int32_t> qpos, indel;
+    std::vector<uint8_t> flag, mq, is_del, allele, bq;
+    std::vector<int64_t> read_off;     // per locus + 1
+    std::string keys;                  // allele keys beyond the six fixed ones, '\n' separated per locus, loci '\0'
+    std::vector<int32_t> n_keys;       // per locus
+    // last smc_bam_planes result (keys / n_keys shared with the pileup result)
+    std::vector<uint32_t> p_meta, p_umi, p_frag, p_dist, p_umi_start;
+    std::vector<smc_locus> p_loci;
+
+    bool load_block(uint64_t coff) {
+        if (fseeko(fh, (off_t)coff, SEEK_SET) != 0) return false;
+        uint8_t hdr[18];
+        if (fread(hdr, 1, 18, fh) != 18) { buf.clear(); off = 0; return false; }
+        if (hdr[0] != 31 || hdr[1] != 139 || hdr[12] != 'B' || hdr[13] != 'C') { err = "not a BGZF block"; return false; }
+        const unsigned xlen = hdr[10] | (hdr[11] << 8), bsize = (hdr[16] | (hdr[17] << 8)) + 1;
+        std::vector<uint8_t> rest(bsize - 18);
+        if (fread(rest.data(), 1, rest.size(), fh) != rest.size()) { err = "truncated BGZF block"; return false; }
+        const size_t c0 = xlen - 6, clen = rest.size() - c0 - 8;
+        const uint32_t isize = rest[rest.size() - 4] | (rest[rest.size() - 3] << 8) | (rest[rest.size() - 2] << 16) |
+                               ((uint32_t)rest[rest.size() - 1] << 24);
+        buf.resize(isize);
+        if (isize) {
+            z_stream zs;
+            memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) { err = "inflateInit2"; return false; }
+            zs.next_in = rest.data() + c0; zs.avail_in = (uInt)clen;
+            zs.next_out = buf.data(); zs.avail_out = isize;
+            const int rc = inflate(&zs, Z_FINISH);
+            inflateEnd(&zs);
+            if (rc != Z_STREAM_END) { err = "inflate failed"; return false; }
+        }
+        off = 0; block_start = coff; next_block = coff + bsize;
+        return true;
+    }
+    void seek(uint64_t v) { load_block(v >> 16); off = v & 0xFFFF; }
+    uint64_t tell() const { return (block_start << 16) | off; }
+    size_t read(void* dst, size_t n) {
+        size_t got = 0;
+        while (got < n) {
+            if (off >= buf.size()) {
+                if (!load_block(next_block)) break;
+                if (buf.empty() && feof(fh)) break;
+                continue;
+            }
+            const size_t take = std::min(n - got, buf.size() - off);
+            memcpy((uint8_t*)dst + got, buf.data() + off, take);
+            off += take; got += take;
+        }
+        return got;
+    }
+};
+
+const char SEQ_CODE[] = "=ACMGRSVTWYHKDBN";
+
+bool parse_record(Bam& b, Aln& a, int32_t& tid) {
+    int32_t bs;
+    if (b.read(&bs, 4) != 4) return false;
+    std::vector<uint8_t> r((size_t)bs);
+    if (b.read(r.data(), r.size()) != r.size()) return false;
+    const uint8_t* p = r.data();
+    int32_t pos, l_seq;
+    memcpy(&tid, p, 4); memcpy(&pos, p + 4, 4);
+    const unsigned l_name = p[8];
+    a.mapq = p[9];
+    const unsigned n_cig = p[12] | (p[13] << 8);
+    a.flag = (uint16_t)(p[14] | (p[15] << 8));
+    memcpy(&l_seq, p + 16, 4);
+    a.pos = pos; a.l_seq = (uint32_t)l_seq;
+    size_t o = 32;
+    a.qname.assign((const char*)p + o, l_name ? l_name - 1 : 0);
+    o += l_name;
+    a.cigar.resize(n_cig);
+    memcpy(a.cigar.data(), p + o, 4 * n_cig);
+    o += 4 * n_cig;
+    a.seq.resize((size_t)l_seq);
+    for (int i = 0; i < l_seq; ++i) a.seq[i] = SEQ_CODE[(p[o + (i >> 1)] >> ((i & 1) ? 0 : 4)) & 15];
+    o += (l_seq + 1) / 2;
+    a.qual.assign(p + o, p + o + l_seq);
+    o += l_seq;
+    a.nm = 0; a.has_nm = 0;
+    while (o + 3 <= r.size()) {   // aux: find NM (smCounter.py:329-334)
+        const char t0 = p[o], t1 = p[o + 1], ty = p[o + 2];
+        o += 3;
+        size_t sz = 0;
+        switch (ty) {
+            case 'A': case 'c': case 'C': sz = 1; break;
+            case 's': case 'S': sz = 2; break;
+            case 'i': case 'I': case 'f': sz = 4; break;
+            case 'Z': case 'H': { while (o < r.size() && p[o]) ++o; ++o; continue; }
+            case 'B': {
+                const char sub = p[o];
+                uint32_t cnt; memcpy(&cnt, p + o + 1, 4);
+                const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                o += 5 + (size_t)cnt * es;
+                continue;
+            }
+            default: o = r.size(); continue;
+        }
+        if (t0 == 'N' && t1 == 'M' && ty != 'A' && ty != 'f') {
+            int64_t v = 0;
+            if (ty == 'c') v = (int8_t)p[o]; else if (ty == 'C') v = p[o];
+            else if (ty == 's') { int16_t x; memcpy(&x, p + o, 2); v = x; }
+            else if (ty == 'S') { uint16_t x; memcpy(&x, p + o, 2); v = x; }
+            else if (ty == 'i') { int32_t x; memcpy(&x, p + o, 4); v = x; }
+            else { uint32_t x; memcpy(&x, p + o, 4); v = x; }
+            a.nm = (uint32_t)v; a.has_nm = 1;
+            break;
+        }
+        o += sz;
+    }
+    int32_t e = pos;
+    for (uint32_t c : a.cigar) { const unsigned op = c & 15; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) e += (int32_t)(c >> 4); }
+    a.end = e;
+    return true;
+}
+
+// Mapped alignments overlapping [start0, end0) on `chrom`, in file order, with run-wide barcode / fragment ids
+// and the per-read CIGAR summaries.  Returns 0, or the negative error code of smc_bam_pileup.
+int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::vector<Aln>& reads, int& n_bc, int& n_pair) {
+    int tid = -1;
+    for (size_t i = 0; i < b.ref_names.size(); ++i) if (b.ref_names[i] == chrom) tid = (int)i;
+    std::unordered_map<std::string, int> bc_ids, pair_ids;
+    if (tid >= 0) {
+        uint64_t voff = b.first_record;
+        if ((size_t)tid < b.lin.size() && !b.lin[(size_t)tid].empty()) {
+            const auto& iv = b.lin[(size_t)tid];
+            long w = (long)std::min<int64_t>(start0 >> 14, (int64_t)iv.size() - 1);
+            while (w >= 0 && iv[(size_t)w] == 0) --w;
+            if (w >= 0) voff = iv[(size_t)w];
+        }
+        b.seek(voff);
+        Aln a;
+        int32_t rt;
+        while (parse_record(b, a, rt)) {
+            if (rt < 0 || rt > tid || (rt == tid && a.pos >= end0)) break;
+            if (rt < tid || (a.flag & 4) || a.cigar.empty()) continue;
+            if (a.end <= start0) continue;
+            // qname -> barcode / read id (smCounter.py:320-325): <readid...>:<UMI>:<x>
+            const std::string& qn = a.qname;
+            const size_t c1 = qn.rfind(':');
+            const size_t c2 = (c1 == std::string::npos || c1 == 0) ? std::string::npos : qn.rfind(':', c1 - 1);
+            if (c2 == std::string::npos) { b.err = "read name '" + qn + "' has fewer than 3 ':' fields"; return -3; }
+            if (a.l_seq == 0) { b.err = "alignment " + qn + " has no sequence"; return -4; }
+            const std::string bc = qn.substr(c2 + 1, c1 - c2 - 1);
+            a.bc_gid = bc_ids.emplace(bc, (int)bc_ids.size()).first->second;
+            a.pair_gid = pair_ids.emplace(bc + "\x01" + qn.substr(0, c2), (int)pair_ids.size()).first->second;
+            a.n_ind = 0; a.qalen = 0;
+            for (uint32_t c : a.cigar) {
+                const unsigned op = c & 15;
+                if (op == 1 || op == 2) a.n_ind += c >> 4;
+                if (op == 0 || op == 1 || op == 7 || op == 8) a.qalen += c >> 4;
+            }
+            a.left_sp = ((a.cigar[0] & 15) == 4) ? (a.cigar[0] >> 4) : 0u;
+            a.oflag = (uint8_t)(((a.flag & 0x40) ? 1 : 0) | ((a.flag & 0x80) ? 2 : 0) | ((a.flag & 0x10) ? 4 : 0) | (a.has_nm ? 8 : 0));
+            reads.push_back(a);
+        }
+    }
+    n_bc = (int)bc_ids.size(); n_pair = (int)pair_ids.size();
+    return 0;
+}
+
+// (qpos, is_del, indel) of `a` at reference position p0 (samtools 0.1.19 resolve_cigar); false = not covered
+inline bool resolve_column(const Aln& a, int64_t p0, int& qpos, bool& isdel, int& indel) {
+    int64_t x = a.pos, y = 0;
+    qpos = -1; indel = 0; isdel = false;
+    for (size_t k = 0; k < a.cigar.size(); ++k) {
+        const unsigned op = a.cigar[k] & 15; const int64_t l = a.cigar[k] >> 4;
+        if (op == 0 || op == 7 || op == 8) {
+            if (x <= p0 && p0 < x + l) {
+                qpos = (int)(y + (p0 - x));
+                if (p0 == x + l - 1 && k + 1 < a.cigar.size()) {
+                    const unsigned nop = a.cigar[k + 1] & 15; const int nl = (int)(a.cigar[k + 1] >> 4);
+                    if (nop == 1) indel = nl; else if (nop == 2) indel = -nl;
+                }
+                return true;
+            }
+            x += l; y += l;
+        } else if (op == 1 || op == 4) {
+            y += l;
+        } else if (op == 2 || op == 3) {
+            if (x <= p0 && p0 < x + l) { qpos = (int)y; isdel = true; return true; }
+            x += l;
+        }
+    }
+    return false;
+}
+
+// allele id of what `a` shows at the column: 0-5 fixed, 6+ index into `extra` (appended on first sight)
+inline int allele_of(const Aln& a, int qpos, bool isdel, int indel, std::vector<std::string>& extra) {
+    if (isdel) return 5;
+    const char site = a.seq[(size_t)qpos];
+    if (indel == 0) {
+        switch (site) { case 'A': return 0; case 'T': return 1; case 'G': return 2; case 'C': return 3; case 'N': return 4; default: break; }
+    }
+    std::string key;
+    if (indel > 0) key = std::string("INS|") + site + "|" + site + a.seq.substr((size_t)qpos + 1, (size_t)indel);
+    else if (indel < 0) key = "D" + std::to_string(-indel) + "|" + site;
+    else key = std::string(1, site);
+    size_t k = 0;
+    while (k < extra.size() && extra[k] != key) ++k;
+    if (k == extra.size()) extra.push_back(key);
+    return 6 + (int)k;
+}
+
+}  // namespace
+
+extern "C" {
+
+int smc_bam_open(const char* path, void** out) {
+    Bam* b = new Bam();
+    b->fh = fopen(path, "rb");
+    if (!b->fh) { delete b; return -1; }
+    b->load_block(0);
+    char magic[4];
+    int32_t l_text, n_ref;
+    if (b->read(magic, 4) != 4 || memcmp(magic, "BAM\1", 4) != 0) { fclose(b->fh); delete b; return -2; }
+    b->read(&l_text, 4);
+    std::vector<char> text((size_t)l_text);
+    b->read(text.data(), text.size());
+    b->read(&n_ref, 4);
+    for (int i = 0; i < n_ref; ++i) {
+        int32_t l_name, l_ref;
+        b->read(&l_name, 4);
+        std::string nm((size_t)l_name, '\0');
+        b->read(&nm[0], (size_t)l_name);
+        nm.resize(l_name ? l_name - 1 : 0);
+        b->read(&l_ref, 4);
+        b->ref_names.push_back(nm);
+        b->ref_lens.push_back(l_ref);
+    }
+    b->first_record = b->tell();
+    // BAI linear index (path + ".bai")
+    std::string bai = std::string(path) + ".bai";
+    FILE* f = fopen(bai.c_str(), "rb");
+    if (f) {
+        fseek(f, 0, SEEK_END);
+        const long sz = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        std::vector<uint8_t> d((size_t)sz);
+        if (fread(d.data(), 1, d.size(), f) == d.size() && sz >= 8 && memcmp(d.data(), "BAI\1", 4) == 0) {
+            size_t o = 8;
+            int32_t nr; memcpy(&nr, d.data() + 4, 4);
+            for (int r = 0; r < nr && o + 4 <= d.size(); ++r) {
+                int32_t n_bin; memcpy(&n_bin, d.data() + o, 4); o += 4;
+                for (int k = 0; k < n_bin; ++k) { int32_t nc; memcpy(&nc, d.data() + o + 4, 4); o += 8 + 16 * (size_t)nc; }
+                int32_t n_intv; memcpy(&n_intv, d.data() + o, 4); o += 4;
+                std::vector<uint64_t> iv((size_t)n_intv);
+                memcpy(iv.data(), d.data() + o, 8 * (size_t)n_intv); o += 8 * (size_t)n_intv;
+                b->lin.push_back(iv);
+            }
+        }
+        fclose(f);
+    }
+    *out = b;
+    return 0;
+}
+
+void smc_bam_close(void* h) {
+    Bam* b = (Bam*)h;
+    if (!b) return;
+    if (b->fh) fclose(b->fh);
+    delete b;
+}
+
+int smc_bam_n_refs(void* h) { return (int)((Bam*)h)->ref_names.size(); }
+const char* smc_bam_ref_name(void* h, int i) { return ((Bam*)h)->ref_names[(size_t)i].c_str(); }
+int64_t smc_bam_ref_len(void* h, int i) { return ((Bam*)h)->ref_lens[(size_t)i]; }
+const char* smc_bam_error(void* h) { return ((Bam*)h)->err.c_str(); }
+
+// Pileup of positions start0, start0+1, ... < end0 on `chrom`; stops after the locus at which the batch
+// reaches max_reads pileup reads.  *n_loci_done = loci emitted.  Returns the number of pileup reads, or < 0:
+// -3 a read name with fewer than 3 ':' fields, -4 no sequence, -5 > 255 alleles at a locus.
+// (An unknown chromosome is not an error: every locus is empty, like pysam's pileup of nothing.)
+int64_t smc_bam_pileup(void* h, const char* chrom, int64_t start0, int64_t end0, int64_t max_reads, int64_t* n_loci_done) {
+    Bam& b = *(Bam*)h;
+    b.umi.clear(); b.frag.clear(); b.nm.clear(); b.n_indel.clear(); b.left_sp.clear(); b.qlen.clear(); b.qalen.clear();
+    b.qpos.clear(); b.indel.clear(); b.flag.clear(); b.mq.clear(); b.is_del.clear(); b.allele.clear(); b.bq.clear();
+    b.read_off.assign(1, 0); b.keys.clear(); b.n_keys.clear();
+    *n_loci_done = 0;
+    std::vector<Aln> reads;
+    int n_bc = 0, n_pair = 0;
+    { const int rc = collect_reads(b, chrom, start0, end0, reads, n_bc, n_pair); if (rc) return rc; }
+    // per-locus dense ids through epoch-stamped tables over the run-wide ids
+    std::vector<int64_t> bc_stamp((size_t)n_bc, -1), pair_stamp((size_t)n_pair, -1);
+    std::vector<int32_t> bc_local((size_t)n_bc), pair_local((size_t)n_pair), n_frag_of;
+    size_t w0 = 0;
+    std::vector<std::string> extra;
+    for (int64_t p0 = start0; p0 < end0; ++p0) {
+        while (w0 < reads.size() && reads[w0].end <= p0) ++w0;
+        extra.clear();
+        n_frag_of.clear();
+        for (size_t ri = w0; ri < reads.size(); ++ri) {
+            const Aln& a = reads[ri];
+            if (a.pos > p0) break;
+            if (p0 >= a.end) continue;
+            int qpos, indel; bool isdel;
+            if (!resolve_column(a, p0, qpos, isdel, indel)) continue;
+            int u, f;
+            if (bc_stamp[(size_t)a.bc_gid] != p0) {
+                bc_stamp[(size_t)a.bc_gid] = p0; u = bc_local[(size_t)a.bc_gid] = (int)n_frag_of.size(); n_frag_of.push_back(0);
+            } else u = bc_local[(size_t)a.bc_gid];
+            if (pair_stamp[(size_t)a.pair_gid] != p0) {
+                pair_stamp[(size_t)a.pair_gid] = p0; f = pair_local[(size_t)a.pair_gid] = n_frag_of[(size_t)u]++;
+            } else f = pair_local[(size_t)a.pair_gid];
+            const int ai = allele_of(a, qpos, isdel, indel, extra);
+            const int bqv = isdel ? 0 : a.qual[(size_t)qpos];
+            if (ai > 255) { b.err = "more than 255 alleles at one locus"; return -5; }
+            b.umi.push_back((uint32_t)u); b.frag.push_back((uint32_t)f);
+            b.flag.push_back(a.oflag);
+            b.mq.push_back(a.mapq); b.nm.push_back(a.nm); b.n_indel.push_back(a.n_ind);
+            b.left_sp.push_back(a.left_sp);
+            b.qlen.push_back(a.l_seq); b.qalen.push_back(a.qalen);
+            b.qpos.push_back(qpos); b.indel.push_back(indel); b.is_del.push_back(isdel ? 1 : 0);
+            b.allele.push_back((uint8_t)ai); b.bq.push_back((uint8_t)bqv);
+        }
+        b.read_off.push_back((int64_t)b.umi.size());
+        b.n_keys.push_back((int32_t)extra.size());
+        for (const std::string& k : extra) { b.keys += k; b.keys += '\n'; }
+        ++*n_loci_done;
+        if ((int64_t)b.umi.size() >= max_reads) break;
+    }
+    return (int64_t)b.umi.size();
+}
+
+int64_t smc_bam_keys_len(void* h) { return (int64_t)((Bam*)h)->keys.size(); }
+
+// copy the last pileup into caller-owned arrays (sizes from smc_bam_pileup / n loci = end0 - start0)
+void smc_bam_copy(void* h, uint32_t* umi, uint32_t* frag, uint8_t* flag, uint8_t* mq, uint32_t* nm, uint32_t* n_indel,
+                  uint32_t* left_sp, uint32_t* qlen, uint32_t* qalen, int32_t* qpos, int32_t* indel, uint8_t* is_del,
+                  uint8_t* allele, uint8_t* bq, int64_t* read_off, int32_t* n_keys, char* keys) {
+    Bam& b = *(Bam*)h;
+    const size_t n = b.umi.size();
+    memcpy(umi, b.umi.data(), 4 * n); memcpy(frag, b.frag.data(), 4 * n); memcpy(flag, b.flag.data(), n);
+    memcpy(mq, b.mq.data(), n); memcpy(nm, b.nm.data(), 4 * n); memcpy(n_indel, b.n_indel.data(), 4 * n);
+    memcpy(left_sp, b.left_sp.data(), 4 * n); memcpy(qlen, b.qlen.data(), 4 * n); memcpy(qalen, b.qalen.data(), 4 * n);
+    memcpy(qpos, b.qpos.data(), 4 * n); memcpy(indel, b.indel.data(), 4 * n); memcpy(is_del, b.is_del.data(), n);
+    memcpy(allele, b.allele.data(), n); memcpy(bq, b.bq.data(), n);
+    memcpy(read_off, b.read_off.data(), 8 * b.read_off.size());
+    memcpy(n_keys, b.n_keys.data(), 4 * b.n_keys.size());
+    memcpy(keys, b.keys.data(), b.keys.size());
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fused decode -> device planes: what bamio.iter_pileup_batches + features.extract_features produce,
+// without the intermediate columns.  Per read (smCounter.py:327-366, :432-452):
+//   meta = allele | bq << 8 | flags << 16 | mapq << 24, flags = R2 | reverse << 1 | mmOK << 2 | kind << 3
+//   dist = distToBcEnd | distToPrimerEnd << 16 (regular bases only, saturated to 16 bits)
+// Reads of a locus are emitted barcode-major (barcode, fragment slot, pileup order), each locus padded to a
+// 4-read boundary; umi_start holds the first read of every barcode (+ closing entry) per locus.
+// refseq: the upper-cased reference letters of [start0, end0).  Loci are processed by `nthreads` threads.
+// Returns pileup reads (unpadded), or < 0: -3/-4/-5 as smc_bam_pileup, -6 first read of a locus has neither
+// READ1 nor READ2, -7 base quality > 126, -8 more than 64 alleles at a locus.
+int64_t smc_bam_planes(void* h, const char* chrom, int64_t start0, int64_t end0, int64_t max_reads, double mismatch_thr,
+                       const char* refseq, int nthreads, int64_t* n_loci_done, int64_t* n_slots, int64_t* n_umi_start) {
+    Bam& b = *(Bam*)h;
+    b.keys.clear(); b.n_keys.clear();
+    *n_loci_done = *n_slots = *n_umi_start = 0;
+    std::vector<Aln> reads;
+    int n_bc = 0, n_pair = 0;
+    const auto t_0 = std::chrono::steady_clock::now();
+    { const int rc = collect_reads(b, chrom, start0, end0, reads, n_bc, n_pair); if (rc) return rc; }
+    const auto t_1 = std::chrono::steady_clock::now();
+    // coverage per position: every read covers exactly [pos, end) (M/=/X/D/N are contiguous on the reference)
+    const int64_t span = end0 - start0;
+    std::vector<int64_t> cov((size_t)span + 1, 0);
+    for (const Aln& a : reads) {
+        const int64_t lo = std::max<int64_t>(a.pos, start0), hi = std::min<int64_t>(a.end, end0);
+        if (lo < hi) { ++cov[(size_t)(lo - start0)]; --cov[(size_t)(hi - start0)]; }
+    }
+    int64_t nl = 0, total = 0, run = 0;
+    std::vector<int64_t> off;   // padded slot offset per locus (+ end)
+    off.push_back(0);
+    std::vector<int64_t> cum;   // unpadded cumulative reads
+    for (int64_t k = 0; k < span; ++k) {
+        run += cov[(size_t)k];
+        total += run;
+        off.push_back(off.back() + (run + 3) / 4 * 4);
+        cum.push_back(total);
+        ++nl;
+        if (total >= max_reads) break;
+    }
+    const int64_t slots = off.back();
+    b.p_meta.assign((size_t)slots, 0); b.p_umi.assign((size_t)slots, 0); b.p_frag.assign((size_t)slots, 0); b.p_dist.assign((size_t)slots, 0);
+    b.p_loci.assign((size_t)nl, smc_locus{});
+    b.n_keys.assign((size_t)nl, 0);
+    const auto t_a = std::chrono::steady_clock::now();
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(nthreads, nl));
+    std::vector<int64_t> cut((size_t)T + 1, nl);   // loci ranges of roughly equal read counts
+    cut[0] = 0;
+    for (int t = 1; t < T; ++t) {
+        const int64_t want = total * t / T;
+        cut[(size_t)t] = std::lower_bound(cum.begin(), cum.end(), want) - cum.begin();
+        cut[(size_t)t] = std::max(cut[(size_t)t], cut[(size_t)t - 1]);
+    }
+    std::vector<std::vector<uint32_t>> t_ustart((size_t)T);
+    std::vector<std::string> t_keys((size_t)T);
+    std::atomic<int> err(0);
+    std::vector<std::string> t_err((size_t)T);
+    auto work = [&](int t) {
+        std::vector<int64_t> bc_stamp((size_t)n_bc, -1), pair_stamp((size_t)n_pair, -1);
+        std::vector<int32_t> bc_local((size_t)n_bc), pair_local((size_t)n_pair), n_frag_of, n_reads_of, slot_base, slot_cnt;
+        std::vector<uint32_t> c_meta, c_umi, c_frag, c_dist;
+        std::vector<std::string> extra;
+        size_t w0 = 0;
+        for (int64_t l = cut[(size_t)t]; l < cut[(size_t)t + 1] && !err.load(std::memory_order_relaxed); ++l) {
+            const int64_t p0 = start0 + l;
+            while (w0 < reads.size() && reads[w0].end <= p0) ++w0;
+            extra.clear(); n_frag_of.clear(); n_reads_of.clear();
+            c_meta.clear(); c_umi.clear(); c_frag.clear(); c_dist.clear();
+            bool r2 = false, first = true;
+            for (size_t ri = w0; ri < reads.size(); ++ri) {
+                const Aln& a = reads[ri];
+                if (a.pos > p0) break;
+                if (p0 >= a.end) continue;
+                int qpos, indel; bool isdel;
+                if (!resolve_column(a, p0, qpos, isdel, indel)) continue;
+                int u, f;
+                if (bc_stamp[(size_t)a.bc_gid] != p0) {
+                    bc_stamp[(size_t)a.bc_gid] = p0; u = bc_local[(size_t)a.bc_gid] = (int)n_frag_of.size();
+                    n_frag_of.push_back(0); n_reads_of.push_back(0);
+                } else u = bc_local[(size_t)a.bc_gid];
+                if (pair_stamp[(size_t)a.pair_gid] != p0) {
+                    pair_stamp[(size_t)a.pair_gid] = p0; f = pair_local[(size_t)a.pair_gid] = n_frag_of[(size_t)u]++;
+                } else f = pair_local[(size_t)a.pair_gid];
+                ++n_reads_of[(size_t)u];
+                const int ai = allele_of(a, qpos, isdel, indel, extra);
+                if (ai >= SMC_MAX_ALLELES) { t_err[(size_t)t] = "more than 64 distinct alleles at " + std::string(chrom) + ":" + std::to_string(p0 + 1); err = -8; return; }
+                const unsigned bq = isdel ? 0u : a.qual[(size_t)qpos];
+                if (bq > 126) { t_err[(size_t)t] = "base quality " + std::to_string(bq) + " > 126 in " + a.qname; err = -7; return; }
+                // pairOrder: R2 wins over R1; neither -> the previous read's value (smCounter.py:359-362)
+                if (a.oflag & 3) r2 = (a.oflag & 2) != 0;
+                else if (first) { t_err[(size_t)t] = "first pileup read at " + std::string(chrom) + ":" + std::to_string(p0 + 1) + " has neither read1 nor read2 set"; err = -6; return; }
+                first = false;
+                const bool rev = (a.oflag & 4) != 0;
+                const int64_t mism = std::max<int64_t>(0, (int64_t)a.nm - (int64_t)a.n_ind);
+                const double mm100 = a.l_seq > 0 ? 100.0 * (double)mism / (double)a.l_seq : 0.0;
+                const unsigned kind = indel > 0 ? 2u : indel < 0 ? 3u : isdel ? 1u : 0u;
+                const unsigned flags = (r2 ? 1u : 0u) | (rev ? 2u : 0u) | (mm100 <= mismatch_thr ? 4u : 0u) | kind << 3;
+                uint32_t dist = 0;
+                if (kind == 0) {
+                    const int64_t rel = (int64_t)qpos - (int64_t)a.left_sp, far = (int64_t)a.qalen - rel;
+                    const int64_t dbc = r2 ? (rev ? rel : far) : (rev ? far : rel), dpr = r2 ? (rev ? far : rel) : 0;
+                    dist = (uint32_t)std::min<int64_t>(65535, std::max<int64_t>(0, dbc)) | (uint32_t)std::min<int64_t>(65535, std::max<int64_t>(0, dpr)) << 16;
+                }
+                c_meta.push_back((uint32_t)ai | bq << 8 | flags << 16 | (uint32_t)a.mapq << 24);
+                c_umi.push_back((uint32_t)u); c_frag.push_back((uint32_t)f); c_dist.push_back(dist);
+            }
+            // fragment slots UMI-major, then a stable counting sort of the reads by slot
+            const size_t nu = n_frag_of.size(), n = c_meta.size();
+            slot_base.assign(nu + 1, 0);
+            for (size_t u = 0; u < nu; ++u) slot_base[u + 1] = slot_base[u] + n_frag_of[u];
+            const size_t nf = (size_t)slot_base[nu];
+            slot_cnt.assign(nf + 1, 0);
+            for (size_t i = 0; i < n; ++i) { c_frag[i] += (uint32_t)slot_base[c_umi[i]]; ++slot_cnt[c_frag[i] + 1]; }
+            for (size_t k = 0; k < nf; ++k) slot_cnt[k + 1] += slot_cnt[k];
+            const size_t o = (size_t)off[(size_t)l];
+            for (size_t i = 0; i < n; ++i) {
+                const size_t d = o + (size_t)slot_cnt[c_frag[i]]++;
+                b.p_meta[d] = c_meta[i]; b.p_umi[d] = c_umi[i]; b.p_frag[d] = c_frag[i]; b.p_dist[d] = c_dist[i];
+            }
+            smc_locus& L = b.p_loci[(size_t)l];
+            L.read_off4 = (uint32_t)(o / 4);
+            L.umi_off = (uint32_t)t_ustart[(size_t)t].size();   // thread-relative; rebased after the join
+            L.n_reads = (int32_t)n; L.n_umi = (int32_t)nu; L.n_frag = (int32_t)nf;
+            uint32_t acc = 0;
+            t_ustart[(size_t)t].push_back(0);
+            for (size_t u = 0; u < nu; ++u) { acc += (uint32_t)n_reads_of[u]; t_ustart[(size_t)t].push_back(acc); }
+            // allele-table facts
+            const char rc = refseq[l];
+            int ra = 255;
+            switch (rc) { case 'A': ra = 0; break; case 'T': ra = 1; break; case 'G': ra = 2; break; case 'C': ra = 3; break; case 'N': ra = 4; break; default: break; }
+            uint64_t mask = 0x1f;
+            for (size_t k = 0; k < extra.size(); ++k) {
+                if (extra[k].size() == 1) { mask |= 1ull << (6 + k); if (ra == 255 && extra[k][0] == rc) ra = 6 + (int)k; }
+                t_keys[(size_t)t] += extra[k]; t_keys[(size_t)t] += '\n';
+            }
+            L.ref_allele = (uint8_t)ra; L.n_alleles = (uint8_t)(6 + extra.size()); L.flags = 0; L.snp_mask = mask;
+            b.n_keys[(size_t)l] = (int32_t)extra.size();
+        }
+    };
+    if (T == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t) th.emplace_back(work, t);
+        for (auto& x : th) x.join();
+    }
+    const auto t_b = std::chrono::steady_clock::now();
+    if (err.load()) { for (const auto& e : t_err) if (!e.empty()) { b.err = e; break; } return err.load(); }
+    b.p_umi_start.clear();
+    for (int t = 0; t < T; ++t) {
+        const uint32_t base = (uint32_t)b.p_umi_start.size();
+        for (int64_t l = cut[(size_t)t]; l < cut[(size_t)t + 1]; ++l) b.p_loci[(size_t)l].umi_off += base;
+        b.p_umi_start.insert(b.p_umi_start.end(), t_ustart[(size_t)t].begin(), t_ustart[(size_t)t].end());
+        b.keys += t_keys[(size_t)t];
+    }
+    *n_loci_done = nl; *n_slots = slots; *n_umi_start = (int64_t)b.p_umi_start.size();
+    if (getenv("SMC_BAM_TIMING")) {
+        const auto t_2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "smc_bam_planes: %zu alignments, %lld loci, %lld reads: fetch %.1f ms, pileup %.1f ms (%d threads) [prep %.1f, threads %.1f]\n",
+                reads.size(), (long long)nl, (long long)total, std::chrono::duration<double, std::milli>(t_1 - t_0).count(),
+                std::chrono::duration<double, std::milli>(t_2 - t_1).count(), T,
+                std::chrono::duration<double, std::milli>(t_a - t_1).count(), std::chrono::duration<double, std::milli>(t_b - t_a).count());
+    }
+    return total;
+}
+
+void smc_bam_planes_copy(void* h, uint32_t* meta, uint32_t* umi, uint32_t* frag, uint32_t* dist, uint32_t* umi_start,
+                         void* loci, int32_t* n_keys, char* keys) {
+    Bam& b = *(Bam*)h;
+    const size_t n = b.p_meta.size();
+    memcpy(meta, b.p_meta.data(), 4 * n); memcpy(umi, b.p_umi.data(), 4 * n);
+    memcpy(frag, b.p_frag.data(), 4 * n); memcpy(dist, b.p_dist.data(), 4 * n);
+    memcpy(umi_start, b.p_umi_start.data(), 4 * b.p_umi_start.size());
+    memcpy(loci, b.p_loci.data(), sizeof(smc_locus) * b.p_loci.size());
+    memcpy(n_keys, b.n_keys.data(), 4 * b.n_keys.size());
+    memcpy(keys, b.keys.data(), b.keys.size());
+}
+
+}  // extern "C"

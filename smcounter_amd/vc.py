@@ -17,13 +17,15 @@ from .pileup import PileupBatch
 EXC_PREFIX = "Exception thrown!"
 
 
-def vc_batch(pb: PileupBatch, params: VcParams, refprov, eng: Optional[_engine.Engine] = None,
+def vc_batch(pb, params: VcParams, refprov, eng: Optional[_engine.Engine] = None,
              device: int = 0) -> List[str]:
+    """pb: a `PileupBatch` (features are extracted here) or an already built `features.DeviceBatch`
+    (bamio.iter_device_batches_native)."""
     own = eng is None
     if own:
         eng = _engine.Engine(device)           # raises loudly without a GPU: there is no CPU path
     try:
-        db = features.extract_features(pb, params)
+        db = pb if isinstance(pb, features.DeviceBatch) else features.extract_features(pb, params)
         out_rows = eng.call_batch_host(db, params)
     finally:
         if own:

@@ -128,3 +128,154 @@ def test_cli_end_to_end_on_gpu(tmp_path):
             assert g == w, l
     vcf = [l for l in open(prefix + ".smCounter.cut.vcf") if not l.startswith("#")]
     assert any(l.split("\t")[1] == str(case["snp_pos"] + 1) and l.split("\t")[4] == case["alt"] for l in vcf)
+
+
+@pytest.mark.parametrize("max_reads", [700, 2_000_000])
+def test_native_decoder_matches_python_decoder(tmp_path, max_reads):
+    """csrc/smc_bam.cpp yields the same chunks, columns and allele tables as the Python decoder."""
+    case = bam_fixture.make_case(str(tmp_path))
+    fa = fasta.FastaFile(case["fasta"])
+    loci = bedops.expand_loci(case["bed"])
+    py = list(bamio.iter_pileup_batches(bamio.BamFile(case["bam"]), fa, loci, max_reads=max_reads))
+    nat = list(bamio.iter_pileup_batches_native(case["bam"], fa, loci, max_reads=max_reads))
+    assert [f for f, _ in py] == [f for f, _ in nat]
+    for (_, a), (_, b) in zip(py, nat):
+        assert a.chrom == b.chrom and a.ref == b.ref and a.alleles == b.alleles
+        assert np.array_equal(a.pos, b.pos) and np.array_equal(a.read_off, b.read_off)
+        for k, _ in bamio._COLS:
+            x, y = getattr(a, k), getattr(b, k)
+            assert x.dtype == y.dtype and np.array_equal(x, y), k
+
+
+def test_native_decoder_errors(tmp_path):
+    p = str(tmp_path / "bad.bam")
+    bamio.write_bam(p, [("chrQ", 100)], [dict(tid=0, pos=5, qname="nocolons", flag=0, mapq=60, cigar=[(0, 4)],
+                                              seq="ACGT", qual=[30] * 4, nm=0)])
+    case = bam_fixture.make_case(str(tmp_path))
+    fa = fasta.FastaFile(case["fasta"])
+    with pytest.raises(bamio.BamError, match="fewer than 3"):
+        list(bamio.iter_pileup_batches_native(p, fa, [("chrQ", "6")]))
+    with pytest.raises(bamio.BamError):
+        bamio.NativeBam(case["fasta"])
+    # unknown chromosome: empty loci, like the Python decoder
+    out = list(bamio.iter_pileup_batches_native(case["bam"], fa, [("chrQ", "1000")]))
+    assert out[0][1].n_loci == 1
+
+
+def _random_bam(tmp, seed, with_bai):
+    """Two chromosomes, reads with random CIGARs (S/M/I/D/N), sparse loci more than 16 kb apart."""
+    rng = np.random.RandomState(seed)
+    refs = [("chrA", 90000), ("chrB", 50000)]
+    seqs = {n: "".join(rng.choice(list("ACGT"), l)) for n, l in refs + [("chrFastaOnly", 100)]}
+    fa_path = str(tmp / "r.fa")
+    with open(fa_path, "w") as fh:
+        for n in seqs:
+            fh.write(">%s\n" % n)
+            for i in range(0, len(seqs[n]), 60):
+                fh.write(seqs[n][i:i + 60] + "\n")
+    centres = [(0, 300), (0, 40000), (0, 88000), (1, 20000), (1, 49000)]
+    recs = []
+    for tid, c in centres:
+        for u in range(25):
+            for fr in range(rng.randint(1, 4)):
+                for mate in (0, 1):
+                    pos = c - rng.randint(20, 120)
+                    cig, ln = [], 0
+                    if rng.rand() < 0.3:
+                        cig.append((4, int(rng.randint(1, 8))))
+                    for _ in range(rng.randint(1, 4)):
+                        cig.append((0, int(rng.randint(20, 60))))
+                        r = rng.rand()
+                        if r < 0.2:
+                            cig.append((1, int(rng.randint(1, 4))))
+                        elif r < 0.4:
+                            cig.append((2, int(rng.randint(1, 6))))
+                        elif r < 0.45:
+                            cig.append((3, int(rng.randint(5, 30))))
+                    if cig[-1][0] != 0:
+                        cig.append((0, int(rng.randint(5, 20))))
+                    qlen = sum(l for op, l in cig if op in (0, 1, 4))
+                    recs.append(dict(tid=tid, pos=max(0, pos), qname="rd%d_%d_%d:x:UMI%02d:0" % (c, u, fr, u),
+                                     flag=(0x40 if mate == 0 else 0x80) | (0x10 if rng.rand() < 0.5 else 0) | 1,
+                                     mapq=int(rng.randint(0, 61)), cigar=cig,
+                                     seq="".join(rng.choice(list("ACGTN"), qlen, p=[.24, .24, .24, .24, .04])),
+                                     qual=[int(x) for x in rng.randint(2, 42, qlen)],
+                                     nm=None if rng.rand() < 0.1 else int(rng.randint(0, 9))))
+    recs.sort(key=lambda r: (r["tid"], r["pos"]))
+    bam = str(tmp / "r.bam")
+    bamio.write_bam(bam, refs, recs, block=4000)
+    if with_bai:
+        bamio.write_bai(bam)
+    loci = []
+    for tid, c in centres:
+        hi = min(refs[tid][1], c + 40)
+        loci += [(refs[tid][0], str(p)) for p in range(max(1, c - 40), hi)]
+    loci += [("chrA", "60000"), ("chrFastaOnly", "5")]          # empty locus / unknown chromosome
+    return bam, fa_path, loci
+
+
+@pytest.mark.parametrize("with_bai", [False, True])
+def test_native_decoder_random_cigars_multi_chrom(tmp_path, with_bai):
+    bam, fa_path, loci = _random_bam(tmp_path, 11, with_bai)
+    fa = fasta.FastaFile(fa_path)
+    if with_bai:
+        assert bamio.BamFile(bam)._lin_index
+    py = pileup.concat([b for _, b in bamio.iter_pileup_batches(bamio.BamFile(bam), fa, loci, max_reads=5000)])
+    nat = pileup.concat([b for _, b in bamio.iter_pileup_batches_native(bam, fa, loci, max_reads=5000)])
+    assert py.n_loci == nat.n_loci == len(loci) and int(py.read_off[-1]) > 10000
+    assert py.chrom == nat.chrom and py.ref == nat.ref and py.alleles == nat.alleles
+    assert np.array_equal(py.read_off, nat.read_off)
+    for k, _ in bamio._COLS:
+        assert np.array_equal(getattr(py, k), getattr(nat, k)), k
+    assert any(len(t) > 6 for t in nat.alleles)
+
+
+def _assert_device_batches_equal(a, b):
+    assert a.loci.dtype == b.loci.dtype
+    for f in a.loci.dtype.names:
+        assert np.array_equal(a.loci[f], b.loci[f]), f
+    for k in ("meta", "umi", "frag", "dist", "umi_start", "pos"):
+        x, y = getattr(a, k), getattr(b, k)
+        assert x.dtype == y.dtype and np.array_equal(x, y), k
+    assert a.chrom == b.chrom and a.ref == b.ref and a.alleles == b.alleles
+
+
+@pytest.mark.parametrize("nthreads", [1, 3])
+@pytest.mark.parametrize("max_reads", [5000, 2_000_000])
+def test_native_fused_planes_match_extract_features(tmp_path, max_reads, nthreads):
+    """smc_bam_planes (decode + features + barcode-major order in one native pass) builds the same
+    DeviceBatch, chunk for chunk, as extract_features over the Python decoder's batches."""
+    bam, fa_path, loci = _random_bam(tmp_path, 23, True)
+    fa = fasta.FastaFile(fa_path)
+    P = VcParams(mismatchThr=4.0)
+    want = [(f, features.extract_features(pb, P))
+            for f, pb in bamio.iter_pileup_batches(bamio.BamFile(bam), fa, loci, max_reads=max_reads)]
+    got = list(bamio.iter_device_batches_native(bam, fa, loci, P, max_reads=max_reads, nthreads=nthreads))
+    assert [f for f, _ in want] == [f for f, _ in got]
+    for (_, a), (_, b) in zip(want, got):
+        _assert_device_batches_equal(a, b)
+    flags = np.concatenate([b.meta for _, b in got]) >> 16 & 0xff
+    assert len(set((flags >> 3).tolist())) == 4 and (flags & 4).any() and not (flags & 4).all()
+
+
+def test_native_fused_planes_fixture_and_errors(tmp_path):
+    case = bam_fixture.make_case(str(tmp_path))
+    fa = fasta.FastaFile(case["fasta"])
+    loci = bedops.expand_loci(case["bed"])
+    P = VcParams()
+    want = features.extract_features(pileup.concat(
+        [b for _, b in bamio.iter_pileup_batches(bamio.BamFile(case["bam"]), fa, loci)]), P)
+    got = list(bamio.iter_device_batches_native(case["bam"], fa, loci, P))
+    assert len(got) == 1
+    _assert_device_batches_equal(want, got[0][1])
+    # a first read with neither READ1 nor READ2: the reference's pairOrder is undefined there
+    p = str(tmp_path / "unpaired.bam")
+    bamio.write_bam(p, [("chrQ", 1000)], [dict(tid=0, pos=5, qname="r:x:U:0", flag=0, mapq=60, cigar=[(0, 4)],
+                                               seq="ACGT", qual=[30] * 4, nm=0)])
+    with pytest.raises(features.PileupError, match="neither read1 nor read2"):
+        list(bamio.iter_device_batches_native(p, fa, [("chrQ", "6")], P))
+    p = str(tmp_path / "hiq.bam")
+    bamio.write_bam(p, [("chrQ", 1000)], [dict(tid=0, pos=5, qname="r:x:U:0", flag=0x40, mapq=60, cigar=[(0, 4)],
+                                               seq="ACGT", qual=[200] * 4, nm=0)])
+    with pytest.raises(features.PileupError, match="base quality"):
+        list(bamio.iter_device_batches_native(p, fa, [("chrQ", "6")], P))
