@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 from smcounter_amd import build, synth, _lib
 so = os.path.join(ROOT, "smcounter_amd", "libsmcounter_hip_stamps.so")
-subprocess.check_call([build.hipcc_path()] + build.HIPCC_FLAGS + ["-DSMC_STAMPS", "-o", so, build.SRC])
+subprocess.check_call([build.hipcc_path()] + build.HIPCC_FLAGS + ["-DSMC_STAMPS", "-o", so, os.environ.get("SMC_SRC", build.SRC)])
 _lib.LIB_PATH = so
 from smcounter_amd import engine
 cfgname = sys.argv[1] if len(sys.argv) > 1 else "C3"

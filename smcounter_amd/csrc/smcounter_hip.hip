@@ -92,9 +92,9 @@ __device__ unsigned long long g_stamps[16];
 #define NT_K1 11  // tallies kept per allele in LDS: the SMC_T_* of the header, without the pad
 
 __device__ __forceinline__ uint32_t lds_hdr_bytes(int a_cap) {
-    // Hdr + tal[a_cap][SMC_NT] + pifx[a_cap] (u64) + mtc[a_cap] + strong[a_cap] + row stage
-    // + lut[LUT_N] doubles
-    return (uint32_t)(sizeof(Hdr) + a_cap * SMC_NT * 4 + a_cap * 8 + a_cap * 4 + a_cap * 4 + sizeof(smc_row) + 128 * 8);
+    // Hdr + tal[a_cap][SMC_NT] + pifx[a_cap] (u64) + mtc[a_cap] + strong[a_cap] + lut[LUT_N] doubles
+    // (the row is staged over the LUT, which is dead by then)
+    return (uint32_t)(sizeof(Hdr) + a_cap * SMC_NT * 4 + a_cap * 8 + a_cap * 4 + a_cap * 4 + 128 * 8);
 }
 
 __device__ __forceinline__ double wave_reduce_mul(double v, int width) {
@@ -196,6 +196,34 @@ typedef unsigned long long lmask;
 #define ADDM(acc, m) asm volatile("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(acc) : "s"((lmask)(m)) : "vcc")   // qualities with an LDS-resident error probability; rarer ones read the global table
 
 
+// calProb for a barcode whose fragments all show ONE allele (the common case) depends only on the fragment
+// count nf: prodP[allele] == rightP bit for bit (same factors, same order), so rightP cancels in the posterior
+// (smCounter.py:83-96) and   post(allele) = (pne + pcr(0)) / (pne + pcr(0) + 3 pcr(nf)),  post(pad) = pcr(nf) / (same)
+// with pcr(c) = 10^(-6 (c + .5) / (nf + 2))  (:79-81, |uniqBase| = 4).  The two -log10(1 - post) values are
+// tabulated once per context for nf < SMC_SIMPLE_N by the device code below; larger barcodes take the general path.
+#define SMC_SIMPLE_N 4096
+__global__ void k_simple_table(double* __restrict__ out, int n) {
+    const int nf = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nf >= n) return;
+    const double pne = 1.0 - 3e-5;
+    double pred0 = 0.0, predpad = 0.0;
+    if (nf > 0) {
+        const double denom = nf + 2.0;
+        const double pcr_self = pcr_of(nf, denom), pcr_zero = pcr_of(0, denom);
+        const double tmp0 = pne + pcr_zero, padOut = pcr_self;
+        double sumP = tmp0;
+        sumP += padOut; sumP += padOut; sumP += padOut;
+        const double post0 = tmp0 / sumP, postp = padOut / sumP;
+        const double x0 = 1.0 - post0;
+        pred0 = x0 > 0.0 ? -log10(x0) : 16.0;                         // :508-510
+        // -log10(1 - t) for the padded keys: t is tiny, the series is exact to < 1e-19 below 1e-6
+        if (postp < 1e-6) predpad = postp * (1.0 + postp * (0.5 + postp * (1.0 / 3.0))) * 0.43429448190325182765;
+        else { const double xp = 1.0 - postp; predpad = xp > 0.0 ? -log10(xp) : 16.0; }
+    }
+    out[2 * nf] = pred0;
+    out[2 * nf + 1] = predpad;
+}
+
 // ---- E stage shared by both locus kernels: ranking and candidates (smCounter.py:534-555), one thread.
 // R points at a zeroed row staged in LDS; misc[] holds the M_* counters.
 __device__ __forceinline__ void finish_row(smc_row* R, const smc_locus& L, int li, int n, int nF, int used, bool downsampled,
@@ -283,9 +311,9 @@ template <int BLOCK, bool GLOBAL_TABLES>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES_PER_EU, 8))) void k_call_loci(
     KParams P, const smc_locus* __restrict__ loci, const int* __restrict__ order, int a_cap,
     const uint32_t* __restrict__ g_meta, const uint32_t* __restrict__ g_umi, const uint32_t* __restrict__ g_frag,
-    const uint32_t* __restrict__ g_dist, const double* __restrict__ g_lut, smc_row* __restrict__ rows,
-    uint8_t* __restrict__ scratch, const int64_t* __restrict__ scratch_off, uint32_t* __restrict__ flt_list,
-    const uint8_t* __restrict__ redo_flag) {
+    const uint32_t* __restrict__ g_dist, const double* __restrict__ g_lut, const double* __restrict__ g_simple,
+    smc_row* __restrict__ rows, uint8_t* __restrict__ scratch, const int64_t* __restrict__ scratch_off,
+    uint32_t* __restrict__ flt_list, const uint8_t* __restrict__ redo_flag) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     // `loci` is this bin's descriptor array in launch order; order[] maps back to the batch index
@@ -305,13 +333,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
     unsigned long long* pifx = (unsigned long long*)(tal + a_cap * SMC_NT);
     uint32_t* mtc = (uint32_t*)(pifx + a_cap);
     uint32_t* strong = mtc + a_cap;
-    smc_row* rowst = (smc_row*)(strong + a_cap);
-    double* lut = (double*)(rowst + 1);                              // [LUT_N]
+    double* lut = (double*)(strong + a_cap);                         // [LUT_N]
+    smc_row* rowst = (smc_row*)lut;                                   // row stage: over the LUT once it is dead
+    static_assert(sizeof(smc_row) <= LUT_N * sizeof(double), "row stage must fit in the LUT");
     unsigned char* tab = GLOBAL_TABLES ? (scratch + scratch_off[blockIdx.x]) : (smem + lds_hdr_bytes(a_cap));
     uint32_t* umi_base = (uint32_t*)tab;                              // [nU+1] first slot of each barcode
     uint32_t* fmin = umi_base + (nU + 1);                             // [nF]
     uint32_t* fmax = fmin + nF;                                       // [nF]
     unsigned char* umi_flag = (unsigned char*)(fmax + nF);            // [nU]
+    // per 64 fragment slots, after the merge: which slots hold a fragment, which of those show the reference allele
+    unsigned long long* cmask = (unsigned long long*)(tab + ((4u * (uint32_t)(nU + 1) + 8u * (uint32_t)nF + (uint32_t)nU + 7u) & ~7u));
 
     STAMP_INIT();
     // first step's reads are requested before the LDS image is initialised (HBM latency overlaps it)
@@ -329,7 +360,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
     // ---- S0: init
     {
         uint32_t* z = (uint32_t*)smem;
-        const int nz = (int)((sizeof(Hdr) + a_cap * 64 + sizeof(smc_row)) / 4);
+        const int nz = (int)((sizeof(Hdr) + a_cap * 64) / 4);
         for (int i = tid; i < nz; i += BLOCK) z[i] = 0;
         for (int i = tid; i < nU; i += BLOCK) { umi_base[i] = 0xFFFFFFFFu; umi_flag[i] = 0; }
         for (int i = tid; i < nF; i += BLOCK) { fmin[i] = 0xFFFFFFFFu; fmax[i] = 0u; }
@@ -472,8 +503,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
     smc_row* out = rows + li;
     if (H->misc[M_ERR] || used == 0) {
         // bad input, or the Zero_Coverage row (smCounter.py:492-494)
+        for (int i = tid; i < (int)(sizeof(smc_row) / 4); i += BLOCK) ((uint32_t*)rowst)[i] = 0u;
+        __syncthreads();
         if (tid == 0) {
-            smc_row* R = rowst;   // zeroed in S0
+            smc_row* R = rowst;
             R->status = H->misc[M_ERR] ? SMC_ST_BAD_INPUT : SMC_ST_ZERO_COVERAGE;
             R->cvg = n;
             R->all_mt = H->misc[M_ALLMT];
@@ -515,7 +548,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
             if (LANES(m_single)) st = ST_PRESENT | (a & 0x3F00u) | PIDX_UNPAIRED;
             if (LANES(m_merge)) st = ST_PRESENT | ST_PAIRED | (a & 0x3F00u) | (q1 < q2 ? q1 : q2);
             if (LANES(m_in & ~m_marked)) fmin[s] = st;
-            const lmask c_ref = m_conc & BAL(a1 == refa), d_ref = m_disc & BAL(a2 == refa);
+            const lmask m_a1ref = BAL(a1 == refa);
+            if (lane == 0 && s < nF) {                                   // chunk masks for the calProb phase
+                const lmask m_live = m_single | m_merge;
+                cmask[2 * (s >> 6)] = m_live;
+                cmask[2 * (s >> 6) + 1] = m_live & m_a1ref;
+            }
+            const lmask c_ref = m_conc & m_a1ref, d_ref = m_disc & BAL(a2 == refa);
             ADDM(conc_ref, c_ref);
             ADDM(disc_ref, d_ref);
             const lmask rare = (m_conc & ~c_ref) | (m_disc & ~d_ref);
@@ -601,6 +640,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
             if (lane == 0) fmin[sb] = present ? make_state(sa, paired ? sq : (int)PIDX_UNPAIRED, paired) : 0u;
         }
         __syncthreads();
+        for (int sb = 0; sb < nF; sb += BLOCK) {                          // chunk masks from the final states
+            const int s = sb + tid;
+            const uint32_t st = s < nF ? fmin[s] : 0u;
+            const lmask m_live = BAL((st & ST_PRESENT) != 0u);
+            const lmask m_lref = m_live & BAL(KEY_ALLELE(st) == (uint32_t)L.ref_allele);
+            if (lane == 0 && s < nF) { cmask[2 * (s >> 6)] = m_live; cmask[2 * (s >> 6) + 1] = m_lref; }
+        }
+        __syncthreads();
     }
 
     STAMP(5);
@@ -617,12 +664,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
 
     // ---- U: per-barcode posterior (calProb, :26-98) and PI / consensus accumulation (:506-532)
     {
-        // lanes per barcode: power of two, enough groups to cover the barcodes
-        // (a function of the locus only, so results do not depend on the launch shape): one lane
-        // walks up to ~48 fragments
-        int G = 1;
-        while (G < WAVE && G < BLOCK && (long long)nF > (long long)SMC_G_FRAGS * G * nU) G <<= 1;
-        const int grp = tid / G, j = tid % G, ngrp = BLOCK / G;
         // fixed-point scale of the PI sums: order-independent, hence bit-reproducible
         int bits = 32 - __clz(used);
         int shift = 58 - bits; if (shift > 48) shift = 48;
@@ -639,7 +680,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
 
         // pass A of one barcode: fragment count, allele set, P(no sequencing error); speculatively also
         // the count and product for the locus's reference allele (the only allele of most barcodes)
-        int Gc = G, jc = j;   // lanes per barcode / lane within the group, per phase
+        int Gc = 8, jc = tid % 8;   // lanes per barcode / lane within the group (general path)
         auto walk = [&](int u, int& b0, int& b1, int& nf, int& cnt_ref, unsigned long long& mask, double& rightP,
                         double& prod_ref) {
             b0 = umi_base[u]; b1 = umi_base[u + 1];
@@ -683,67 +724,60 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
             mask = ((unsigned long long)mhi << 32) | mlo;
         };
 
-        // ---- phase 0: every barcode; those holding only the reference allele (nearly all) are scored
-        // here with straight-line code, the others are queued (fmax[] is dead after the merge)
+        // ---- phase 0: one lane per barcode.  Fragment count and "every fragment shows the reference allele"
+        // come from the chunk masks the merge left (no walk); such barcodes (nearly all) are scored from the
+        // per-count table, the others are queued (fmax[] is dead after the merge)
         uint32_t* worklist = fmax;
-        for (int u = grp; u < nU; u += ngrp) {
+        for (int u = tid; u < nU; u += BLOCK) {
             if (!umi_flag[u]) continue;                                // not a key of bcDict
-            int b0, b1, nf, cnt_ref;
-            unsigned long long mask;
-            double rightP, prod_ref;
-            walk(u, b0, b1, nf, cnt_ref, mask, rightP, prod_ref);
-            if (j == 0) { ufrag += nf; c3 += nf >= 3; c5 += nf >= 5; c7 += nf >= 7; c10 += nf >= 10; }
+            const uint32_t b0 = umi_base[u], b1 = umi_base[u + 1];
+            int nf = 0, cr = 0;
+            unsigned long long live1 = 0;                              // live slots of the last chunk touched
+            uint32_t c1 = 0;
+            for (uint32_t c = b0 >> 6; c <= ((b1 - 1u) >> 6); ++c) {
+                const uint32_t lo = b0 > 64u * c ? b0 - 64u * c : 0u, hi = b1 < 64u * c + 64u ? b1 - 64u * c : 64u;
+                const unsigned long long range = (hi >= 64u ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
+                const unsigned long long lv = cmask[2 * c] & range;
+                nf += __popcll(lv);
+                cr += __popcll(cmask[2 * c + 1] & range);
+                if (lv) { live1 = lv; c1 = c; }
+            }
+            ufrag += nf; c3 += nf >= 3; c5 += nf >= 5; c7 += nf >= 7; c10 += nf >= 10;
             if (nf <= P.mt_drop) {                                     // :28-32 -> all four posteriors 0
-                if (j == 0) {
-                    touch_lo |= 0xFu;                                  // finalDict gets A,T,G,C (+ -0.0)
-                    if (nf == 1) {                                     // tie -> single-fragment rule, :521-523
-                        const int a = __ffsll((long long)mask) - 1;
-                        if (a < 4) mt_acc[a]++; else atomicAdd(&mtc[a], 1u);
-                    }
+                touch_lo |= 0xFu;                                      // finalDict gets A,T,G,C (+ -0.0)
+                if (nf == 1) {                                         // tie -> single-fragment rule, :521-523
+                    const int a = (int)KEY_ALLELE(fmin[64u * c1 + (uint32_t)(__ffsll((long long)live1) - 1)]);
+                    if (a < 4) mt_acc[a]++; else atomicAdd(&mtc[a], 1u);
                 }
                 continue;
             }
-            if (!(refa < 64 && mask == (1ull << refa))) {
-                if (j == 0) worklist[atomicAdd(&H->misc[M_NCOMPLEX], 1u)] = (uint32_t)u;
+            if (!(refa < 64 && cr == nf && nf < SMC_SIMPLE_N)) {
+                worklist[atomicAdd(&H->misc[M_NCOMPLEX], 1u)] = (uint32_t)u;
                 continue;
             }
             // one existing allele (the reference), three padded keys (:49-54): nk = 4
             const unsigned long long padmask = refa < 4 ? (0xFull & ~(1ull << refa)) : 0x7ull;
-            const double denom = nf + 2.0;                             // :80
-            const double pcr_self = pcr_of(nf, denom), pcr_zero = pcr_of(0, denom);
-            const double tmp0 = pne * prod_ref + rightP * pcr_zero;    // :86
-            const double padOut = rightP * pcr_self;                   // :88-91
-            double sumP = tmp0;
-            sumP += padOut; sumP += padOut; sumP += padOut;
-            const double post0 = sumP <= 0 ? 0.0 : tmp0 / sumP, postp = sumP <= 0 ? 0.0 : padOut / sumP;
-            const double x0 = 1.0 - post0;
-            const double pred0 = x0 > 0.0 ? -log10(x0) : 16.0;         // :508-510
-            // -log10(1 - t) for the padded keys: t is tiny, the series is exact to < 1e-19 below 1e-6
-            double predpad;
-            if (postp < 1e-6) predpad = postp * (1.0 + postp * (0.5 + postp * (1.0 / 3.0))) * 0.43429448190325182765;
-            else { const double xp = 1.0 - postp; predpad = xp > 0.0 ? -log10(xp) : 16.0; }
-            if (j == 0) {
-                const long long fx0 = (long long)(pred0 * fxscale + 0.5), fxp = (long long)(predpad * fxscale + 0.5);
-                if (refa >= 4) atomicAdd(&pifx[refa], (unsigned long long)fx0);
+            const double pred0 = g_simple[2 * nf], predpad = g_simple[2 * nf + 1];
+            const long long fx0 = (long long)(pred0 * fxscale + 0.5), fxp = (long long)(predpad * fxscale + 0.5);
+            if (refa >= 4) atomicAdd(&pifx[refa], (unsigned long long)fx0);
 #pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    if (a == refa) pi_acc[a] += fx0;
-                    else if ((padmask >> a) & 1ull) pi_acc[a] += fxp;
-                }
-                const unsigned long long uq = mask | padmask;
-                touch_lo |= (uint32_t)uq; touch_hi |= (uint32_t)(uq >> 32);
-                if (pred0 > predpad) {                                 // unique maximum (:514-519)
-                    const bool str = pred0 > P.smt;
-                    if (refa < 4) {
+            for (int a = 0; a < 4; ++a) {
+                if (a == refa) pi_acc[a] += fx0;
+                else if ((padmask >> a) & 1ull) pi_acc[a] += fxp;
+            }
+            const unsigned long long uq = (1ull << refa) | padmask;
+            touch_lo |= (uint32_t)uq; touch_hi |= (uint32_t)(uq >> 32);
+            if (pred0 > predpad) {                                     // unique maximum (:514-519)
+                const bool str = pred0 > P.smt;
+                if (refa < 4) {
 #pragma unroll
-                        for (int a = 0; a < 4; ++a) if (a == refa) { mt_acc[a]++; st_acc[a] += str; }
-                    } else { atomicAdd(&mtc[refa], 1u); if (str) atomicAdd(&strong[refa], 1u); }
-                } else if (nf == 1) {                                  // :521-523
-                    if (refa < 4) {
+                    for (int a = 0; a < 4; ++a) if (a == refa) { mt_acc[a]++; st_acc[a] += str; }
+                } else { atomicAdd(&mtc[refa], 1u); if (str) atomicAdd(&strong[refa], 1u); }
+            } else if (nf == 1) {                                      // :521-523
+                if (refa < 4) {
 #pragma unroll
-                        for (int a = 0; a < 4; ++a) if (a == refa) mt_acc[a]++;
-                    } else atomicAdd(&mtc[refa], 1u);
-                }
+                    for (int a = 0; a < 4; ++a) if (a == refa) mt_acc[a]++;
+                } else atomicAdd(&mtc[refa], 1u);
             }
         }
         __syncthreads();
@@ -752,8 +786,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         // ---- phase 1: the queued barcodes (more than one allele, or not the reference), general path
         // (8 lanes per barcode here: few barcodes, short walks, and idle waves skip the phase)
         const int n_complex = (int)H->misc[M_NCOMPLEX];
-        Gc = 8;
-        jc = tid % Gc;
         const int grp1 = tid / Gc, ngrp1 = BLOCK / Gc;
         for (int w = grp1; w < n_complex; w += ngrp1) {
             const int u = (int)worklist[w];
@@ -963,7 +995,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         STAMP(7);
         if (SMC_ABLATE == 4) return;
 
-        // ---- E: ranking and candidates (:534-555), one thread
+        // ---- E: ranking and candidates (:534-555), one thread; the row is staged over the (dead) LUT
+        for (int i = tid; i < (int)(sizeof(smc_row) / 4); i += BLOCK) ((uint32_t*)rowst)[i] = 0u;
+        __syncthreads();
         if (tid == 0)
             finish_row(rowst, L, li, n, nF, used, (int)n_bc > P.ds, fxscale, H->misc, tal, pifx, mtc, strong, flt_list);
         __syncthreads();
@@ -1550,14 +1584,17 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 struct smc_ctx {
     int device;
     double* lut;   // 10^(-q/10), q = 0..255
+    double* simple; // [SMC_SIMPLE_N][2]: -log10(1 - posterior) of a one-allele barcode by fragment count
     int max_lds;   // bytes of LDS a workgroup may use
 };
 
 static size_t host_hdr_bytes(int a_cap) {
-    return sizeof(Hdr) + (size_t)a_cap * SMC_NT * 4 + (size_t)a_cap * 8 + (size_t)a_cap * 4 + (size_t)a_cap * 4 + sizeof(smc_row) + 128 * 8;
+    return sizeof(Hdr) + (size_t)a_cap * SMC_NT * 4 + (size_t)a_cap * 8 + (size_t)a_cap * 4 + (size_t)a_cap * 4 + 128 * 8;
 }
 static size_t table_bytes(const smc_locus& L) {
     size_t b = 4 * ((size_t)L.n_umi + 1) + 8 * (size_t)L.n_frag + (size_t)L.n_umi;
+    b = (b + 7) & ~(size_t)7;
+    b += 16 * (((size_t)L.n_frag + 63) / 64);             // chunk masks (live, live & reference allele)
     return (b + 15) & ~(size_t)15;
 }
 
@@ -1606,7 +1643,7 @@ static hipError_t launch_bin(const Bin& b, const KParams& kp, const smc_plan* p,
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)b.order.size()), dim3(BLOCK), b.lds_bytes, st, kp, b.d_loci, b.d_order, b.a_cap,
-                       meta, umi, frag, dist, p->ctx->lut, rows, b.d_scratch, b.d_scratch_off, p->d_flt_list,
+                       meta, umi, frag, dist, p->ctx->lut, p->ctx->simple, rows, b.d_scratch, b.d_scratch_off, p->d_flt_list,
                        p->use_sorted ? p->d_redo : (const uint8_t*)nullptr);
     return hipGetLastError();
 }
@@ -1641,6 +1678,10 @@ int smc_create(int device, smc_ctx** out) {
     for (int q = 0; q < 256; ++q) h[q] = pow(10.0, -q / 10.0);   // smCounter.py:469
     HIPCHK(hipMalloc(&c->lut, sizeof h));
     HIPCHK(hipMemcpy(c->lut, h, sizeof h, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&c->simple, sizeof(double) * 2 * SMC_SIMPLE_N));
+    hipLaunchKernelGGL(k_simple_table, dim3(SMC_SIMPLE_N / 256), dim3(256), 0, 0, c->simple, SMC_SIMPLE_N);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
     *out = c;
     return SMC_OK;
 }
@@ -1649,6 +1690,7 @@ void smc_destroy(smc_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipFree(c->lut);
+    (void)hipFree(c->simple);
     delete c;
 }
 
