@@ -154,6 +154,7 @@ __device__ __forceinline__ uint32_t make_key(int idx, int allele, int bq) {
 // a sequencer) take a slow path through the global table.
 #define ST_PRESENT 0x80000000u
 #define ST_PAIRED 0x40000000u
+#define ST_HAD 0x20000000u     // slot had included reads (its barcode is a key of bcDict) but the fragment was deleted
 #define PIDX_UNPAIRED 127u
 __device__ __forceinline__ uint32_t make_state(int allele, int bq, bool paired) {
     return ST_PRESENT | (paired ? ST_PAIRED : 0u) | ((uint32_t)allele << 8) | (uint32_t)bq;
@@ -310,7 +311,7 @@ __device__ __forceinline__ void finish_row(smc_row* R, const smc_locus& L, int l
 template <int BLOCK, bool GLOBAL_TABLES>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES_PER_EU, 8))) void k_call_loci(
     KParams P, const smc_locus* __restrict__ loci, const int* __restrict__ order, int a_cap,
-    const uint32_t* __restrict__ g_meta, const uint32_t* __restrict__ g_umi, const uint32_t* __restrict__ g_frag,
+    const uint32_t* __restrict__ g_meta, const uint32_t* __restrict__ g_umi_start, const uint32_t* __restrict__ g_frag,
     const uint32_t* __restrict__ g_dist, const double* __restrict__ g_lut, const double* __restrict__ g_simple,
     smc_row* __restrict__ rows, uint8_t* __restrict__ scratch, const int64_t* __restrict__ scratch_off,
     uint32_t* __restrict__ flt_list, const uint8_t* __restrict__ redo_flag) {
@@ -323,7 +324,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
     const smc_locus L = loci[blockIdx.x];
     const int n = L.n_reads, nU = L.n_umi, nF = L.n_frag, nA = L.n_alleles;
     const uint4* meta4 = (const uint4*)(g_meta + 4ll * L.read_off4);
-    const uint4* umi4 = (const uint4*)(g_umi + 4ll * L.read_off4);
     const uint4* frag4 = (const uint4*)(g_frag + 4ll * L.read_off4);
     const uint4* dist4 = (const uint4*)(g_dist + 4ll * L.read_off4);
 
@@ -347,8 +347,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
     STAMP_INIT();
     // first step's reads are requested before the LDS image is initialised (HBM latency overlaps it)
     const int n4 = (n + 3) >> 2;
-    uint4 m4, u4, f4, d4;
-    if (tid < n4) { m4 = meta4[tid]; u4 = umi4[tid]; f4 = frag4[tid]; d4 = dist4[tid]; }
+    uint4 m4, f4, d4;
+    if (tid < n4) { m4 = meta4[tid]; f4 = frag4[tid]; d4 = dist4[tid]; }
     // quality -> error-probability table: requested now, parked in registers, stored to LDS after the
     // scan (its first reader is the calProb phase), so no phase waits on this load
     double lut_reg[(LUT_N + BLOCK - 1) / BLOCK];
@@ -362,9 +362,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         uint32_t* z = (uint32_t*)smem;
         const int nz = (int)((sizeof(Hdr) + a_cap * 64) / 4);
         for (int i = tid; i < nz; i += BLOCK) z[i] = 0;
-        for (int i = tid; i < nU; i += BLOCK) { umi_base[i] = 0xFFFFFFFFu; umi_flag[i] = 0; }
         for (int i = tid; i < nF; i += BLOCK) { fmin[i] = 0xFFFFFFFFu; fmax[i] = 0u; }
-        if (tid == 0) umi_base[nU] = (uint32_t)nF;
+        // first read of every barcode (+ closing entry); S2 turns it into the first fragment slot
+        const uint32_t* ustart = g_umi_start + L.umi_off;
+        for (int i = tid; i <= nU; i += BLOCK) umi_base[i] = ustart[i];
     }
     __syncthreads();
     STAMP(0);
@@ -384,20 +385,20 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         const uint32_t refa = L.ref_allele;
         for (int qb = 0; qb < n4; qb += BLOCK) {
             const int q = qb + tid;
-            const uint4 cm = m4, cu = u4, cf = f4, cd = d4;
+            const uint4 cm = m4, cf = f4, cd = d4;
             {   // prefetch the next step while this one is processed
                 const int qn = q + BLOCK;
-                if (qn < n4) { m4 = meta4[qn]; u4 = umi4[qn]; f4 = frag4[qn]; d4 = dist4[qn]; }
+                if (qn < n4) { m4 = meta4[qn]; f4 = frag4[qn]; d4 = dist4[qn]; }
             }
-            const uint32_t ms[4] = {cm.x, cm.y, cm.z, cm.w}, us[4] = {cu.x, cu.y, cu.z, cu.w};
+            const uint32_t ms[4] = {cm.x, cm.y, cm.z, cm.w};
             const uint32_t fs[4] = {cf.x, cf.y, cf.z, cf.w}, ds[4] = {cd.x, cd.y, cd.z, cd.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int i = 4 * q + k;
-                const uint32_t mw = ms[k], u = us[k], f = fs[k], dw = ds[k];
+                const uint32_t mw = ms[k], f = fs[k], dw = ds[k];
                 const uint32_t a = mw & 0xffu, kind = (mw >> 19) & 3u;
                 const lmask m_valid = BAL(i < n);                         // n4 = ceil(n/4): q < n4 follows
-                const lmask m_ok = m_valid & BAL(u < (uint32_t)nU) & BAL(f < (uint32_t)nF) & BAL(a < (uint32_t)nA);
+                const lmask m_ok = m_valid & BAL(f < (uint32_t)nF) & BAL(a < (uint32_t)nA);
                 err_m |= m_valid & ~m_ok;
                 const lmask m_base = BAL(kind == SMC_KIND_BASE), m_gap = BAL(kind == SMC_KIND_GAP);
                 const lmask m_qok = BAL((int)((mw >> 8) & 0xffu) >= P.min_bq);            // :378 first term / :428
@@ -452,10 +453,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                         }
                     }
                 }
-                if (LANES(m_ok)) {
-                    if (umi_base[u] > f) atomicMin(&umi_base[u], f);     // converges after a few reads
+                {
                     if (LANES(m_inc)) {
-                        if (!umi_flag[u]) umi_flag[u] = 1;
                         uint32_t bq_eff = LANES(m_gap) ? (uint32_t)P.min_bq : ((mw >> 8) & 0xffu);         // :418
                         bq_eff = bq_eff < PIDX_UNPAIRED ? bq_eff : PIDX_UNPAIRED - 1u;   // contract: quality <= 126
                         const uint32_t key = ((uint32_t)i << 14) | (a << 8) | bq_eff;
@@ -482,27 +481,37 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
     STAMP(1);
     if (SMC_ABLATE == 2) return;
 
-    // ---- S2: barcode bookkeeping: allMT (:482), size of bcDict, slot ranges must be ordered
+    // ---- S2: first fragment slot of every barcode = slot of its first read (reads are barcode-major, slots
+    // ascending inside a barcode); read ranges and slot ranges must be ordered and cover [0, n) / [0, nF)
     {
-        uint32_t nbc = 0, allmt = 0, bad = 0;
+        const uint32_t* frag = g_frag + 4ll * L.read_off4;
+        uint32_t bad = 0;
+        for (int ub = 0; ub < nU; ub += BLOCK) {
+            const int u = ub + tid;
+            uint32_t b0 = 0;
+            if (u < nU) {
+                const uint32_t r0 = umi_base[u], r1 = umi_base[u + 1];
+                bad |= !(r0 < r1 && r1 <= (uint32_t)n) || (u == 0 && r0 != 0) || (u == nU - 1 && r1 != (uint32_t)n);
+                b0 = r0 < (uint32_t)n ? frag[r0] : 0xFFFFFFFFu;
+            }
+            __syncthreads();                                            // every r1 of this step is read
+            if (u < nU) umi_base[u] = b0;
+        }
+        if (tid == 0) umi_base[nU] = (uint32_t)nF;
+        __syncthreads();
         for (int u = tid; u < nU; u += BLOCK) {
             const uint32_t b0 = umi_base[u], b1 = umi_base[u + 1];
-            nbc += umi_flag[u];
-            allmt += b0 != 0xFFFFFFFFu;
-            bad |= (b0 == 0xFFFFFFFFu) || b1 <= b0 || (u == 0 && b0 != 0);
+            bad |= b1 <= b0 || b1 > (uint32_t)nF || (u == 0 && b0 != 0);
         }
-        nbc = wave_reduce_add((int)nbc, WAVE);
-        allmt = wave_reduce_add((int)allmt, WAVE);
+        if (nU == 0 && n != 0) bad = 1;
         if (__builtin_amdgcn_ballot_w64(bad != 0) && lane == 0) H->misc[M_ERR] = 1;
-        if (lane == 0) { atomicAdd(&H->misc[M_NBC], nbc); atomicAdd(&H->misc[M_ALLMT], allmt); }
+        if (tid == 0) H->misc[M_ALLMT] = (uint32_t)nU;                  // allMT (:482): every barcode has a read
     }
     __syncthreads();
     STAMP(2);
-    const uint32_t n_bc = H->misc[M_NBC];
-    const int used = (int)n_bc < P.ds ? (int)n_bc : P.ds;             // smCounter.py:489
     smc_row* out = rows + li;
-    if (H->misc[M_ERR] || used == 0) {
-        // bad input, or the Zero_Coverage row (smCounter.py:492-494)
+    if (H->misc[M_ERR] || H->misc[M_NINC] == 0) {
+        // bad input, or no read enters bcDict: the Zero_Coverage row (smCounter.py:489-494)
         for (int i = tid; i < (int)(sizeof(smc_row) / 4); i += BLOCK) ((uint32_t*)rowst)[i] = 0u;
         __syncthreads();
         if (tid == 0) {
@@ -545,6 +554,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
             c += (uint32_t)__popcll(m_single) + 2u * (uint32_t)__popcll(m_pair);
             // state: first read's allele; prob = max(prob_new, prob_old) <=> min quality (:473)
             uint32_t st = 0u;
+            if (LANES(m_has)) st = ST_HAD;                                // discordant pair: deleted (:477-479)
             if (LANES(m_single)) st = ST_PRESENT | (a & 0x3F00u) | PIDX_UNPAIRED;
             if (LANES(m_merge)) st = ST_PRESENT | ST_PAIRED | (a & 0x3F00u) | (q1 < q2 ? q1 : q2);
             if (LANES(m_in & ~m_marked)) fmin[s] = st;
@@ -582,7 +592,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         // Some read name has >= 3 included alignments on this locus (rare): redo the fragment table,
         // mark those fragments, resolve the others as above and replay the marked ones in read order.
         const uint32_t* meta = g_meta + 4ll * L.read_off4;
-        const uint32_t* umi = g_umi + 4ll * L.read_off4;
         const uint32_t* frag = g_frag + 4ll * L.read_off4;
         for (int i = tid; i < nF; i += BLOCK) { fmin[i] = 0xFFFFFFFFu; fmax[i] = 0u; }
         for (int a = tid; a < a_cap; a += BLOCK) tal[a * SMC_NT + SMC_T_CONCORD] = tal[a * SMC_NT + SMC_T_DISCORD] = 0;
@@ -637,7 +646,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                     }
                 }
             }
-            if (lane == 0) fmin[sb] = present ? make_state(sa, paired ? sq : (int)PIDX_UNPAIRED, paired) : 0u;
+            if (lane == 0) fmin[sb] = present ? make_state(sa, paired ? sq : (int)PIDX_UNPAIRED, paired) : ST_HAD;
         }
         __syncthreads();
         for (int sb = 0; sb < nF; sb += BLOCK) {                          // chunk masks from the final states
@@ -651,21 +660,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
     }
 
     STAMP(5);
-    // ---- down-sampling stand-in (non-parity; the reference random.samples, :496-498):
-    // keep the `ds` lowest barcode ids among bcDict's keys.
-    if ((int)n_bc > P.ds) {
-        if (tid == 0) {
-            int k = 0;
-            for (int u = 0; u < nU; ++u)
-                if (umi_flag[u]) { if (k >= P.ds) umi_flag[u] = 0; ++k; }
-        }
-        __syncthreads();
-    }
-
     // ---- U: per-barcode posterior (calProb, :26-98) and PI / consensus accumulation (:506-532)
     {
         // fixed-point scale of the PI sums: order-independent, hence bit-reproducible
-        int bits = 32 - __clz(used);
+        // (sized for the most barcodes the locus can use, so it does not wait for the bcDict count)
+        const int ubound = nU < P.ds ? nU : P.ds;
+        int bits = 32 - __clz(ubound);
         int shift = 58 - bits; if (shift > 48) shift = 48;
         const double fxscale = (double)(1ull << shift);
         long long pi_acc[4] = {0, 0, 0, 0};
@@ -728,12 +728,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         // come from the chunk masks the merge left (no walk); such barcodes (nearly all) are scored from the
         // per-count table, the others are queued (fmax[] is dead after the merge)
         uint32_t* worklist = fmax;
-        for (int u = tid; u < nU; u += BLOCK) {
-            if (!umi_flag[u]) continue;                                // not a key of bcDict
+        // fragment count / reference-only count / "is a key of bcDict" (:467-468: has an included read, even if
+        // every fragment was deleted later) of barcode u
+        auto barcode_counts = [&](int u, int& nf, int& cr, unsigned long long& live1, uint32_t& c1) -> bool {
             const uint32_t b0 = umi_base[u], b1 = umi_base[u + 1];
-            int nf = 0, cr = 0;
-            unsigned long long live1 = 0;                              // live slots of the last chunk touched
-            uint32_t c1 = 0;
+            nf = 0; cr = 0; live1 = 0; c1 = 0;
             for (uint32_t c = b0 >> 6; c <= ((b1 - 1u) >> 6); ++c) {
                 const uint32_t lo = b0 > 64u * c ? b0 - 64u * c : 0u, hi = b1 < 64u * c + 64u ? b1 - 64u * c : 64u;
                 const unsigned long long range = (hi >= 64u ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
@@ -742,6 +741,42 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                 cr += __popcll(cmask[2 * c + 1] & range);
                 if (lv) { live1 = lv; c1 = c; }
             }
+            if (nf) return true;
+            for (uint32_t sl = b0; sl < b1; ++sl)
+                if (fmin[sl] & ST_HAD) return true;
+            return false;
+        };
+        // More barcodes than the cap can only happen when nU > ds: then a first pass finds bcDict's keys and the
+        // down-sampling stand-in (non-parity; the reference random.samples, :496-498) keeps the ds lowest ids.
+        const bool two_pass = nU > P.ds;
+        if (two_pass) {
+            uint32_t nb = 0;
+            for (int u = tid; u < nU; u += BLOCK) {
+                int nf, cr; unsigned long long l1; uint32_t c1;
+                const bool key = barcode_counts(u, nf, cr, l1, c1);
+                umi_flag[u] = key;
+                nb += key;
+            }
+            nb = (uint32_t)wave_reduce_add((int)nb, WAVE);
+            if (lane == 0 && nb) atomicAdd(&H->misc[M_NBC], nb);
+            __syncthreads();
+            if ((int)H->misc[M_NBC] > P.ds) {
+                if (tid == 0) {
+                    int k = 0;
+                    for (int u = 0; u < nU; ++u)
+                        if (umi_flag[u]) { if (k >= P.ds) umi_flag[u] = 0; ++k; }
+                }
+                __syncthreads();
+            }
+        }
+        uint32_t nb1 = 0;
+        for (int u = tid; u < nU; u += BLOCK) {
+            int nf, cr;
+            unsigned long long live1;                                  // live slots of the last chunk touched
+            uint32_t c1;
+            const bool key = barcode_counts(u, nf, cr, live1, c1);
+            if (two_pass ? !umi_flag[u] : !key) continue;              // not a (kept) key of bcDict
+            ++nb1;
             ufrag += nf; c3 += nf >= 3; c5 += nf >= 5; c7 += nf >= 7; c10 += nf >= 10;
             if (nf <= P.mt_drop) {                                     // :28-32 -> all four posteriors 0
                 touch_lo |= 0xFu;                                      // finalDict gets A,T,G,C (+ -0.0)
@@ -779,6 +814,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                     for (int a = 0; a < 4; ++a) if (a == refa) mt_acc[a]++;
                 } else atomicAdd(&mtc[refa], 1u);
             }
+        }
+        if (!two_pass) {
+            nb1 = (uint32_t)wave_reduce_add((int)nb1, WAVE);
+            if (lane == 0 && nb1) atomicAdd(&H->misc[M_NBC], nb1);
         }
         __syncthreads();
         STAMP(6);
@@ -999,7 +1038,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         for (int i = tid; i < (int)(sizeof(smc_row) / 4); i += BLOCK) ((uint32_t*)rowst)[i] = 0u;
         __syncthreads();
         if (tid == 0)
-            finish_row(rowst, L, li, n, nF, used, (int)n_bc > P.ds, fxscale, H->misc, tal, pifx, mtc, strong, flt_list);
+        {
+            const int n_bc = (int)H->misc[M_NBC];
+            finish_row(rowst, L, li, n, nF, n_bc < P.ds ? n_bc : P.ds /* usedMT, :489 */, n_bc > P.ds, fxscale, H->misc, tal,
+                       pifx, mtc, strong, flt_list);
+        }
         __syncthreads();
         const uint32_t* src = (const uint32_t*)rowst;
         uint32_t* dst = (uint32_t*)out;
@@ -1635,7 +1678,7 @@ struct smc_plan {
 };
 
 template <int BLOCK, bool GT>
-static hipError_t launch_bin(const Bin& b, const KParams& kp, const smc_plan* p, const uint32_t* meta, const uint32_t* umi,
+static hipError_t launch_bin(const Bin& b, const KParams& kp, const smc_plan* p, const uint32_t* meta, const uint32_t* umi_start,
                              const uint32_t* frag, const uint32_t* dist, smc_row* rows, hipStream_t st) {
     auto kern = k_call_loci<BLOCK, GT>;
     if (b.lds_bytes > 64 * 1024) {
@@ -1643,7 +1686,7 @@ static hipError_t launch_bin(const Bin& b, const KParams& kp, const smc_plan* p,
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)b.order.size()), dim3(BLOCK), b.lds_bytes, st, kp, b.d_loci, b.d_order, b.a_cap,
-                       meta, umi, frag, dist, p->ctx->lut, p->ctx->simple, rows, b.d_scratch, b.d_scratch_off, p->d_flt_list,
+                       meta, umi_start, frag, dist, p->ctx->lut, p->ctx->simple, rows, b.d_scratch, b.d_scratch_off, p->d_flt_list,
                        p->use_sorted ? p->d_redo : (const uint8_t*)nullptr);
     return hipGetLastError();
 }
@@ -1873,11 +1916,11 @@ int smc_plan_run(smc_plan* p, const smc_params* prm, const uint32_t* meta, const
         if (timed) HIPCHK(hipEventRecord(p->ev0[slot], st));
         hipError_t e = hipSuccess;
         switch (b.cls) {
-            case 0: e = launch_bin<64, false>(b, kp, p, meta, umi, frag, dist, rows, st); break;
-            case 1: e = launch_bin<SMC_CLS1_BLOCK, false>(b, kp, p, meta, umi, frag, dist, rows, st); break;
-            case 2: e = launch_bin<512, false>(b, kp, p, meta, umi, frag, dist, rows, st); break;
-            case 3: e = launch_bin<1024, false>(b, kp, p, meta, umi, frag, dist, rows, st); break;
-            default: e = launch_bin<1024, true>(b, kp, p, meta, umi, frag, dist, rows, st); break;
+            case 0: e = launch_bin<64, false>(b, kp, p, meta, umi_start, frag, dist, rows, st); break;
+            case 1: e = launch_bin<SMC_CLS1_BLOCK, false>(b, kp, p, meta, umi_start, frag, dist, rows, st); break;
+            case 2: e = launch_bin<512, false>(b, kp, p, meta, umi_start, frag, dist, rows, st); break;
+            case 3: e = launch_bin<1024, false>(b, kp, p, meta, umi_start, frag, dist, rows, st); break;
+            default: e = launch_bin<1024, true>(b, kp, p, meta, umi_start, frag, dist, rows, st); break;
         }
         if (e != hipSuccess) return fail(SMC_E_HIP, std::string("k_call_loci launch: ") + hipGetErrorString(e));
         if (timed) { HIPCHK(hipEventRecord(p->ev1[slot], st)); p->n_timed++; }
