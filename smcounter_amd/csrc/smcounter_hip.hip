@@ -114,6 +114,46 @@ __device__ __forceinline__ long long wave_reduce_add64(long long v, int width) {
     return v;
 }
 
+// ---- reductions through DPP (one VALU instruction per step, no LDS round trip, unlike __shfl = ds_bpermute).
+// Callers keep whole 8-lane groups (grp8_*) or the whole wavefront (wave_*) active.
+#define DPP_XOR1 0xB1          // quad_perm:[1,0,3,2]
+#define DPP_XOR2 0x4E          // quad_perm:[2,3,0,1]
+#define DPP_HALF_MIRROR 0x141  // lane i <- lane 7-i of its 8
+#define DPP_MIRROR 0x140       // lane i <- lane 15-i of its row
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    return __hiloint2double(dpp_i32<CTRL>(__double2hiint(v)), dpp_i32<CTRL>(__double2loint(v)));
+}
+template <int CTRL>
+__device__ __forceinline__ long long dpp_i64(long long v) {
+    return (long long)(((unsigned long long)(uint32_t)dpp_i32<CTRL>((int)(v >> 32)) << 32) | (uint32_t)dpp_i32<CTRL>((int)v));
+}
+__device__ __forceinline__ int grp8_add(int v) { v += dpp_i32<DPP_XOR1>(v); v += dpp_i32<DPP_XOR2>(v); v += dpp_i32<DPP_HALF_MIRROR>(v); return v; }
+__device__ __forceinline__ uint32_t grp8_or(uint32_t v) {
+    v |= (uint32_t)dpp_i32<DPP_XOR1>((int)v); v |= (uint32_t)dpp_i32<DPP_XOR2>((int)v); v |= (uint32_t)dpp_i32<DPP_HALF_MIRROR>((int)v);
+    return v;
+}
+__device__ __forceinline__ double grp8_mul(double v) { v *= dpp_f64<DPP_XOR1>(v); v *= dpp_f64<DPP_XOR2>(v); v *= dpp_f64<DPP_HALF_MIRROR>(v); return v; }
+// whole-wavefront totals, returned wave-uniform (row totals by DPP, the four rows added on the scalar unit)
+__device__ __forceinline__ int wave_add(int v) {
+    v = grp8_add(v); v += dpp_i32<DPP_MIRROR>(v);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
+    v = grp8_or(v); v |= (uint32_t)dpp_i32<DPP_MIRROR>((int)v);
+    return (uint32_t)(__builtin_amdgcn_readlane((int)v, 0) | __builtin_amdgcn_readlane((int)v, 16) | __builtin_amdgcn_readlane((int)v, 32) | __builtin_amdgcn_readlane((int)v, 48));
+}
+__device__ __forceinline__ long long wave_add64(long long v) {
+    v += dpp_i64<DPP_XOR1>(v); v += dpp_i64<DPP_XOR2>(v); v += dpp_i64<DPP_HALF_MIRROR>(v); v += dpp_i64<DPP_MIRROR>(v);
+    long long t = 0;
+#pragma unroll
+    for (int r = 0; r < 64; r += 16)
+        t += (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), r) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, r));
+    return t;
+}
+
 // block-wide exclusive prefix sum over arr[0..n) in place; returns the total (in all threads).
 template <int BLOCK>
 __device__ uint32_t block_exclusive_scan(uint32_t* arr, int n, uint32_t* tmp /*>= 32 u32 in LDS*/) {
@@ -466,7 +506,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         }
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            const uint32_t v = (uint32_t)wave_reduce_add((int)accv[k], WAVE);
+            const uint32_t v = (uint32_t)wave_add((int)accv[k]);
             if (lane == 0 && v && refa < (uint32_t)nA) atomicAdd(&tal[refa * SMC_NT + k], v);
         }
         if (lane == 0 && n_inc_s) atomicAdd(&H->misc[M_NINC], n_inc_s);
@@ -573,8 +613,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                 if (LANES(m_disc & ~d_ref)) atomicAdd(&tal[a2 * SMC_NT + SMC_T_DISCORD], 1u);
             }
         }
-        conc_ref = (uint32_t)wave_reduce_add((int)conc_ref, WAVE);
-        disc_ref = (uint32_t)wave_reduce_add((int)disc_ref, WAVE);
+        conc_ref = (uint32_t)wave_add((int)conc_ref);
+        disc_ref = (uint32_t)wave_add((int)disc_ref);
         if (lane == 0 && refa < (uint32_t)nA) {
             if (conc_ref) atomicAdd(&tal[refa * SMC_NT + SMC_T_CONCORD], conc_ref);
             if (disc_ref) atomicAdd(&tal[refa * SMC_NT + SMC_T_DISCORD], disc_ref);
@@ -680,7 +720,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
 
         // pass A of one barcode: fragment count, allele set, P(no sequencing error); speculatively also
         // the count and product for the locus's reference allele (the only allele of most barcodes)
-        int Gc = 8, jc = tid % 8;   // lanes per barcode / lane within the group (general path)
+        constexpr int Gc = 8;         // lanes per barcode on the general path (grp8_* reductions)
+        const int jc = tid % Gc;
         auto walk = [&](int u, int& b0, int& b1, int& nf, int& cnt_ref, unsigned long long& mask, double& rightP,
                         double& prod_ref) {
             b0 = umi_base[u]; b1 = umi_base[u + 1];
@@ -716,11 +757,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                 rightP = (rp[0] * rp[1]) * (rp[2] * rp[3]);
                 prod_ref = (pr[0] * pr[1]) * (pr[2] * pr[3]);
             }
-            nf = wave_reduce_add(nf, Gc);
-            cnt_ref = wave_reduce_add(cnt_ref, Gc);
-            const uint32_t mlo = wave_reduce_or((uint32_t)mk, Gc), mhi = wave_reduce_or((uint32_t)(mk >> 32), Gc);
-            rightP = wave_reduce_mul(rightP, Gc);
-            prod_ref = wave_reduce_mul(prod_ref, Gc);
+            nf = grp8_add(nf);
+            cnt_ref = grp8_add(cnt_ref);
+            const uint32_t mlo = grp8_or((uint32_t)mk), mhi = grp8_or((uint32_t)(mk >> 32));
+            rightP = grp8_mul(rightP);
+            prod_ref = grp8_mul(prod_ref);
             mask = ((unsigned long long)mhi << 32) | mlo;
         };
 
@@ -757,7 +798,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                 umi_flag[u] = key;
                 nb += key;
             }
-            nb = (uint32_t)wave_reduce_add((int)nb, WAVE);
+            nb = (uint32_t)wave_add((int)nb);
             if (lane == 0 && nb) atomicAdd(&H->misc[M_NBC], nb);
             __syncthreads();
             if ((int)H->misc[M_NBC] > P.ds) {
@@ -816,7 +857,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
             }
         }
         if (!two_pass) {
-            nb1 = (uint32_t)wave_reduce_add((int)nb1, WAVE);
+            nb1 = (uint32_t)wave_add((int)nb1);
             if (lane == 0 && nb1) atomicAdd(&H->misc[M_NBC], nb1);
         }
         __syncthreads();
@@ -824,7 +865,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
 
         // ---- phase 1: the queued barcodes (more than one allele, or not the reference), general path
         // (8 lanes per barcode here: few barcodes, short walks, and idle waves skip the phase)
-        const int n_complex = (int)H->misc[M_NCOMPLEX];
+        const int n_complex = SMC_ABLATE == 5 ? 0 : (int)H->misc[M_NCOMPLEX];   // 5: diagnostic, skips the general path
         const int grp1 = tid / Gc, ngrp1 = BLOCK / Gc;
         for (int w = grp1; w < n_complex; w += ngrp1) {
             const int u = (int)worklist[w];
@@ -869,8 +910,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        cnta[k] = wave_reduce_add(cnta[k], Gc);
-                        proda[k] = wave_reduce_mul(proda[k], Gc);
+                        cnta[k] = grp8_add(cnta[k]);
+                        proda[k] = grp8_mul(proda[k]);
                     }
                 }
                 // PCR-error terms (:79-81); min over the other keys == value at their max count
@@ -962,8 +1003,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                             prod *= same ? 1.0 - p : p;
                         }
                     }
-                    cnt = wave_reduce_add(cnt, Gc);
-                    prod = wave_reduce_mul(prod, Gc);
+                    cnt = grp8_add(cnt);
+                    prod = grp8_mul(prod);
                 };
                 int max1 = -1, max2 = -1, arg1 = -1;
                 for (unsigned long long mm = mask; mm; mm &= mm - 1) {
@@ -1012,18 +1053,18 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         // flush lane accumulators (order-independent integer adds)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            const long long p = wave_reduce_add64(pi_acc[a], WAVE);
-            const int m = wave_reduce_add(mt_acc[a], WAVE), s = wave_reduce_add(st_acc[a], WAVE);
+            const long long p = wave_add64(pi_acc[a]);
+            const int m = wave_add(mt_acc[a]), s = wave_add(st_acc[a]);
             if (lane == 0) {
                 if (p) atomicAdd(&pifx[a], (unsigned long long)p);
                 if (m) atomicAdd(&mtc[a], (uint32_t)m);
                 if (s) atomicAdd(&strong[a], (uint32_t)s);
             }
         }
-        c3 = wave_reduce_add(c3, WAVE); c5 = wave_reduce_add(c5, WAVE);
-        c7 = wave_reduce_add(c7, WAVE); c10 = wave_reduce_add(c10, WAVE);
-        ufrag = wave_reduce_add(ufrag, WAVE);
-        touch_lo = wave_reduce_or(touch_lo, WAVE); touch_hi = wave_reduce_or(touch_hi, WAVE);
+        c3 = wave_add(c3); c5 = wave_add(c5);
+        c7 = wave_add(c7); c10 = wave_add(c10);
+        ufrag = wave_add(ufrag);
+        touch_lo = wave_or(touch_lo); touch_hi = wave_or(touch_hi);
         if (lane == 0) {
             atomicAdd(&H->misc[M_MT3], (uint32_t)c3); atomicAdd(&H->misc[M_MT5], (uint32_t)c5);
             atomicAdd(&H->misc[M_MT7], (uint32_t)c7); atomicAdd(&H->misc[M_MT10], (uint32_t)c10);
