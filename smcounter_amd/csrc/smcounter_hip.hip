@@ -265,6 +265,18 @@ __global__ void k_simple_table(double* __restrict__ out, int n) {
     out[2 * nf + 1] = predpad;
 }
 
+// ---- fixed-point PI sums: value * 2^shift as 64-bit integers (order-independent adds).  Conversions are spelled
+// out (5 / 3 instructions) instead of the generic 64-bit casts (~ 50 each).
+__device__ __forceinline__ long long to_fx(double pred, double fxscale) {
+    const double t = pred * fxscale + 0.5;                   // in [0, 2^53): pred <= 16, shift <= 48
+    const double hi_d = floor(t * 0x1p-32);
+    const uint32_t hi = (uint32_t)hi_d, lo = (uint32_t)fma(hi_d, -0x1p32, t);
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double from_fx(unsigned long long v, double inv /* 2^-shift */) {
+    return fma((double)(uint32_t)(v >> 32), 0x1p32, (double)(uint32_t)v) * inv;   // one rounding, like the cast
+}
+
 // ---- E stage shared by both locus kernels: ranking and candidates (smCounter.py:534-555), one thread.
 // R points at a zeroed row staged in LDS; misc[] holds the M_* counters.
 __device__ __forceinline__ void finish_row(smc_row* R, const smc_locus& L, int li, int n, int nF, int used, bool downsampled,
@@ -274,8 +286,8 @@ __device__ __forceinline__ void finish_row(smc_row* R, const smc_locus& L, int l
     const int nA = L.n_alleles;
     const unsigned long long touched = ((unsigned long long)misc[M_TOUCH_HI] << 32) | misc[M_TOUCH_LO];
     const int nkeys = __popcll(touched);
-    const double inv = 1.0 / fxscale;
-    auto PI = [&](int a) { return (double)(long long)pifx[a] * inv; };
+    const double inv = 1.0 / fxscale;                               // exact: fxscale is a power of two
+    auto PI = [&](int a) { return from_fx(pifx[a], inv); };
     auto rank = [&](int a) {
         const int r8[6] = {0, 5, 6, 2, 7, 4}, r32[6] = {0, 21, 6, 2, 15, 20};
         return a < 6 ? (nkeys <= 5 ? r8[a] : r32[a]) : 64 + a;
@@ -323,9 +335,8 @@ __device__ __forceinline__ void finish_row(smc_row* R, const smc_locus& L, int l
     const int alt = best == ref ? second : best;                                   // :541
     fill(R->cand[0], alt);
     if (alt >= 0 && R->cand[0].pi >= 5 && filterable(alt)) R->cand[0].flt_applied = 1;   // :549
-    const double mf1 = best >= 0 ? 1.0 * mtc[best] / used : 0.0;
-    const double mf2 = second >= 0 ? 1.0 * mtc[second] / used : 0.0;
-    if (best >= 0 && second >= 0 && best != ref && second != ref && mf1 >= 0.45 && mf2 >= 0.45) {   // :555
+    if (best >= 0 && second >= 0 && best != ref && second != ref && 1.0 * mtc[best] / used >= 0.45 &&
+        1.0 * mtc[second] / used >= 0.45) {                                        // :553-555
         R->biallelic = 1;
         fill(R->cand[1], second);
         if (R->cand[1].pi >= 5 && filterable(second)) R->cand[1].flt_applied = 1;   // :563
@@ -834,7 +845,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
             // one existing allele (the reference), three padded keys (:49-54): nk = 4
             const unsigned long long padmask = refa < 4 ? (0xFull & ~(1ull << refa)) : 0x7ull;
             const double pred0 = g_simple[2 * nf], predpad = g_simple[2 * nf + 1];
-            const long long fx0 = (long long)(pred0 * fxscale + 0.5), fxp = (long long)(predpad * fxscale + 0.5);
+            const long long fx0 = to_fx(pred0, fxscale), fxp = to_fx(predpad, fxscale);
             if (refa >= 4) atomicAdd(&pifx[refa], (unsigned long long)fx0);
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
@@ -965,12 +976,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                     for (int k = 0; k < 4; ++k)
                         if (k < n_exist) {
                             const int a = ida[k];
-                            const long long fx = (long long)(predv[k] * fxscale + 0.5);
+                            const long long fx = to_fx(predv[k], fxscale);
                             if (a < 4) pi_acc[a] += fx; else atomicAdd(&pifx[a], (unsigned long long)fx);
                             if (predv[k] == mx) { ++n_max; cons = a; }                 // :514
                         }
                     if (npad) {
-                        const long long fx = (long long)(predpad * fxscale + 0.5);
+                        const long long fx = to_fx(predpad, fxscale);
 #pragma unroll
                         for (int a = 0; a < 4; ++a)
                             if ((padmask >> a) & 1ull) {
@@ -1036,7 +1047,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                     if (pred > mx) { mx = pred; n_max = 1; cons = a; }
                     else if (pred == mx) ++n_max;
                     if (jc == 0) {
-                        const long long fx = (long long)(pred * fxscale + 0.5);
+                        const long long fx = to_fx(pred, fxscale);
                         if (a < 4) pi_acc[a] += fx; else atomicAdd(&pifx[a], (unsigned long long)fx);
                     }
                 }
@@ -1375,7 +1386,7 @@ __global__ __launch_bounds__(WAVE) void k_call_sorted(
                     double predpad;
                     if (postp < 1e-6) predpad = postp * (1.0 + postp * (0.5 + postp * (1.0 / 3.0))) * 0.43429448190325182765;
                     else { const double xp = 1.0 - postp; predpad = xp > 0.0 ? -log10(xp) : 16.0; }
-                    const long long fx0 = (long long)(pred0 * fxscale + 0.5), fxp = (long long)(predpad * fxscale + 0.5);
+                    const long long fx0 = to_fx(pred0, fxscale), fxp = to_fx(predpad, fxscale);
                     if (refa >= 4) atomicAdd(&pifx[refa], (unsigned long long)fx0);
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
@@ -1485,13 +1496,13 @@ __global__ __launch_bounds__(WAVE) void k_call_sorted(
                 for (int k = 0; k < 4; ++k)
                     if (k < n_exist) {
                         const int a = ida[k];
-                        const long long fx = (long long)(predv[k] * fxscale + 0.5);
+                        const long long fx = to_fx(predv[k], fxscale);
                         if (a < 4) { for (int m = 0; m < 4; ++m) if (m == a) pi_acc[m] += fx; }
                         else atomicAdd(&pifx[a], (unsigned long long)fx);
                         if (predv[k] == mx) { ++n_max; cons = a; }                 // :514
                     }
                 if (npad) {
-                    const long long fx = (long long)(predpad * fxscale + 0.5);
+                    const long long fx = to_fx(predpad, fxscale);
 #pragma unroll
                     for (int a = 0; a < 4; ++a)
                         if ((padmask >> a) & 1ull) {
