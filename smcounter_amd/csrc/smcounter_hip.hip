@@ -933,43 +933,62 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                         if (cnta[k] > max1) { max2 = max1; arg2 = arg1; max1 = cnta[k]; arg1 = k; }
                         else if (cnta[k] > max2) { max2 = cnta[k]; arg2 = k; }
                     }
-                double prodpcr = 1.0, tmpv[4] = {0, 0, 0, 0}, pcrv[4] = {0, 0, 0, 0}, sumP = 0.0;
+                // The transcendental chains run lane-parallel: lane k (< n_exist) of the barcode's first quad owns
+                // existing allele k, lane n_exist owns the zero-count PCR term and then the padded keys; values
+                // are exchanged by quad broadcasts (DPP).  Every value is produced by the same instruction
+                // sequence whichever lane computes it, so results do not depend on the lane assignment.
+                const int myc = jc == 0 ? cnta[0] : jc == 1 ? cnta[1] : jc == 2 ? cnta[2] : jc == 3 ? cnta[3] : 0;
+                const double mypcr = pcr_of(myc, denom);               // lanes >= n_exist: count 0
+                double pcrv[4];
+                pcrv[0] = dpp_f64<0x00>(mypcr); pcrv[1] = dpp_f64<0x55>(mypcr);
+                pcrv[2] = dpp_f64<0xAA>(mypcr); pcrv[3] = dpp_f64<0xFF>(mypcr);
+                double prodpcr = 1.0;
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (k < n_exist) { pcrv[k] = pcr_of(cnta[k], denom); prodpcr *= pcrv[k]; }
+                    if (k < n_exist) prodpcr *= pcrv[k];
                 // the "other keys" term needs the PCR value at the largest count among the other keys:
                 // that is one of the values just computed (equal counts give bit-equal values), or the
-                // zero-count value when the only other keys are padded ones
-                const double pcr0 = n_exist == 1 ? pcr_of(0, denom) : 0.0;
+                // zero-count value (lane 1's) when the only other keys are padded ones
+                const double pcr0 = n_exist == 1 ? pcrv[1] : 0.0;
+                const double padOut = rightP * prodpcr;                // :88-91
+                double mytmp = padOut;                                 // lane n_exist: the padded keys
+                {
+                    const int oi = (jc == arg1) ? arg2 : arg1;
+                    double po = pcr0;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) po = (m == oi) ? pcrv[m] : po;
+                    const double myprod = jc == 0 ? proda[0] : jc == 1 ? proda[1] : jc == 2 ? proda[2] : proda[3];
+                    if (jc < n_exist) mytmp = pne * myprod + rightP * po;                 // :86
+                }
+                double tmpv[4];
+                tmpv[0] = dpp_f64<0x00>(mytmp); tmpv[1] = dpp_f64<0x55>(mytmp);
+                tmpv[2] = dpp_f64<0xAA>(mytmp); tmpv[3] = dpp_f64<0xFF>(mytmp);
+                double sumP = 0.0;
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (k < n_exist) {
-                        const int oi = (k == arg1) ? arg2 : arg1;
-                        double po = pcr0;
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) po = (m == oi) ? pcrv[m] : po;
-                        tmpv[k] = pne * proda[k] + rightP * po;                       // :86
-                        sumP += tmpv[k];
-                    }
-                const double padOut = rightP * prodpcr;                // :88-91
+                    if (k < n_exist) sumP += tmpv[k];
                 for (int k = 0; k < npad; ++k) sumP += padOut;
                 // posteriors -> -log10(1-p) (:95-96, :508-510)
-                double predv[4] = {0, 0, 0, 0}, mx = -1.0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (k < n_exist) {
-                        const double post = sumP <= 0 ? 0.0 : tmpv[k] / sumP;
-                        const double x = 1.0 - post;
-                        predv[k] = x > 0.0 ? -log10(x) : 16.0;
-                        if (predv[k] > mx) mx = predv[k];
-                    }
-                double predpad = 0.0;
-                if (npad) {
-                    const double post = sumP <= 0 ? 0.0 : padOut / sumP;
-                    if (post < 1e-6) predpad = post * (1.0 + post * (0.5 + post * (1.0 / 3.0))) * 0.43429448190325182765;
-                    else { const double x = 1.0 - post; predpad = x > 0.0 ? -log10(x) : 16.0; }
-                    if (predpad > mx) mx = predpad;
+                const double mypost = sumP <= 0 ? 0.0 : mytmp / sumP;
+                double mypred;
+                if (jc >= n_exist && mypost < 1e-6) {
+                    // padded keys: t is tiny, the series is exact to < 1e-19 below 1e-6
+                    mypred = mypost * (1.0 + mypost * (0.5 + mypost * (1.0 / 3.0))) * 0.43429448190325182765;
+                } else {
+                    const double x = 1.0 - mypost;
+                    mypred = x > 0.0 ? -log10(x) : 16.0;
                 }
+                double predv[4], mx = -1.0;
+                predv[0] = dpp_f64<0x00>(mypred); predv[1] = dpp_f64<0x55>(mypred);
+                predv[2] = dpp_f64<0xAA>(mypred); predv[3] = dpp_f64<0xFF>(mypred);
+                double predpad = 0.0;
+                if (npad) predpad = n_exist == 1 ? predv[1] : n_exist == 2 ? predv[2] : predv[3];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (k >= n_exist) predv[k] = 0.0;
+                    else if (predv[k] > mx) mx = predv[k];
+                }
+                if (npad && predpad > mx) mx = predpad;
                 if (jc == 0) {
                     int n_max = 0, cons = -1;
 #pragma unroll
