@@ -734,17 +734,17 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         constexpr int Gc = 8;         // lanes per barcode on the general path (grp8_* reductions)
         const int jc = tid % Gc;
         auto walk = [&](int u, int& b0, int& b1, int& nf, int& cnt_ref, unsigned long long& mask, double& rightP,
-                        double& prod_ref) {
+                        double& prod_ref, double& prod_x) {
             b0 = umi_base[u]; b1 = umi_base[u + 1];
             // pass A: fragment count, allele set, P(no sequencing error); speculatively also the
             // count and product for the locus's reference allele (the only allele of most barcodes)
             nf = 0; cnt_ref = 0;
             unsigned long long mk = 0;
-            rightP = 1.0; prod_ref = 1.0;
+            rightP = 1.0; prod_ref = 1.0; prod_x = 1.0;
             {
                 // four slots per lane per step, independent partial products (the walk is a chain of
                 // dependent LDS reads and FP64 multiplies: instruction-level parallelism hides it)
-                double rp[4] = {1.0, 1.0, 1.0, 1.0}, pr[4] = {1.0, 1.0, 1.0, 1.0};
+                double rp[4] = {1.0, 1.0, 1.0, 1.0}, pr[4] = {1.0, 1.0, 1.0, 1.0}, px[4] = {1.0, 1.0, 1.0, 1.0};
                 for (int s0 = b0 + jc; s0 < b1; s0 += 4 * Gc) {
                     uint32_t st[4];
 #pragma unroll
@@ -763,16 +763,19 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                         mk |= present ? (1ull << a) : 0ull;
                         rp[t] *= present ? q1 : 1.0;
                         pr[t] *= present ? (same ? q1 : pv[t]) : 1.0;
+                        px[t] *= present ? (same ? pv[t] : q1) : 1.0;   // P(reads | the other allele), if there is just one
                     }
                 }
                 rightP = (rp[0] * rp[1]) * (rp[2] * rp[3]);
                 prod_ref = (pr[0] * pr[1]) * (pr[2] * pr[3]);
+                prod_x = (px[0] * px[1]) * (px[2] * px[3]);
             }
             nf = grp8_add(nf);
             cnt_ref = grp8_add(cnt_ref);
             const uint32_t mlo = grp8_or((uint32_t)mk), mhi = grp8_or((uint32_t)(mk >> 32));
             rightP = grp8_mul(rightP);
             prod_ref = grp8_mul(prod_ref);
+            prod_x = grp8_mul(prod_x);
             mask = ((unsigned long long)mhi << 32) | mlo;
         };
 
@@ -882,8 +885,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
             const int u = (int)worklist[w];
             int b0, b1, nf, cnt_ref;
             unsigned long long mask;
-            double rightP, prod_ref;
-            walk(u, b0, b1, nf, cnt_ref, mask, rightP, prod_ref);
+            double rightP, prod_ref, prod_x;
+            walk(u, b0, b1, nf, cnt_ref, mask, rightP, prod_ref, prod_x);
             const int n_exist = __popcll(mask);
             int npad = n_exist < 4 ? 4 - n_exist : 0;
             unsigned long long padmask = 0;
@@ -903,6 +906,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                 }
                 if (refa < 64 && mask == (1ull << refa)) {
                     cnta[0] = cnt_ref; proda[0] = prod_ref;            // speculation hit: no second pass
+                } else if (refa < 64 && n_exist == 2 && ((mask >> refa) & 1ull)) {
+                    // the reference allele and one other (the usual queued barcode): the walk's two
+                    // speculative products are exactly the two P(reads | allele), no second pass
+                    const bool ref_first = ida[0] == refa;
+                    cnta[0] = ref_first ? cnt_ref : nf - cnt_ref; cnta[1] = ref_first ? nf - cnt_ref : cnt_ref;
+                    proda[0] = ref_first ? prod_ref : prod_x; proda[1] = ref_first ? prod_x : prod_ref;
                 } else {
                     // pass B: per existing allele, count and P(reads | allele)  (:62-77)
                     for (int s = b0 + jc; s < b1; s += Gc) {
@@ -989,24 +998,29 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                     else if (predv[k] > mx) mx = predv[k];
                 }
                 if (npad && predpad > mx) mx = predpad;
+                // PI sums (:512): each owning lane adds its own value to its own accumulators (the lane
+                // accumulators are summed over the wavefront at the end, integer adds: order-free)
+                if (jc <= n_exist && jc < 4) {
+                    const long long fx = to_fx(mypred, fxscale);
+                    if (jc < n_exist) {
+                        const int a = jc == 0 ? ida[0] : jc == 1 ? ida[1] : jc == 2 ? ida[2] : ida[3];
+                        if (a >= 4) atomicAdd(&pifx[a], (unsigned long long)fx);
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) pi_acc[b] += (b == a) ? fx : 0ll;
+                    } else if (npad) {
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) pi_acc[b] += ((padmask >> b) & 1ull) ? fx : 0ll;
+                    }
+                }
                 if (jc == 0) {
                     int n_max = 0, cons = -1;
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        if (k < n_exist) {
-                            const int a = ida[k];
-                            const long long fx = to_fx(predv[k], fxscale);
-                            if (a < 4) pi_acc[a] += fx; else atomicAdd(&pifx[a], (unsigned long long)fx);
-                            if (predv[k] == mx) { ++n_max; cons = a; }                 // :514
-                        }
-                    if (npad) {
-                        const long long fx = to_fx(predpad, fxscale);
+                        if (k < n_exist && predv[k] == mx) { ++n_max; cons = ida[k]; }  // :514
+                    if (npad && predpad == mx) {
 #pragma unroll
                         for (int a = 0; a < 4; ++a)
-                            if ((padmask >> a) & 1ull) {
-                                pi_acc[a] += fx;
-                                if (predpad == mx) { ++n_max; cons = a; }
-                            }
+                            if ((padmask >> a) & 1ull) { ++n_max; cons = a; }
                     }
                     const unsigned long long uq = mask | padmask;
                     touch_lo |= (uint32_t)uq; touch_hi |= (uint32_t)(uq >> 32);
