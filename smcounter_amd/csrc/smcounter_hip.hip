@@ -279,29 +279,32 @@ __device__ __forceinline__ double from_fx(unsigned long long v, double inv /* 2^
 
 // ---- E stage shared by both locus kernels: ranking and candidates (smCounter.py:534-555), one thread.
 // R points at a zeroed row staged in LDS; misc[] holds the M_* counters.
+// Called either by one thread (lane 0, step 1) or by every lane of one wavefront (lane, step 64): the scalar logic
+// is then computed redundantly by all lanes (same instructions, same values) and the tally copies are spread over
+// the lanes.
 __device__ __forceinline__ void finish_row(smc_row* R, const smc_locus& L, int li, int n, int nF, int used, bool downsampled,
                                            double fxscale, const uint32_t* misc, const uint32_t* tal,
                                            const unsigned long long* pifx, const uint32_t* mtc, const uint32_t* strong,
-                                           uint32_t* flt_list) {
+                                           uint32_t* flt_list, int lane, int step) {
     const int nA = L.n_alleles;
     const unsigned long long touched = ((unsigned long long)misc[M_TOUCH_HI] << 32) | misc[M_TOUCH_LO];
     const int nkeys = __popcll(touched);
     const double inv = 1.0 / fxscale;                               // exact: fxscale is a power of two
     auto PI = [&](int a) { return from_fx(pifx[a], inv); };
+    // py2 dict slot order of the fixed keys A,T,G,C,N,DEL: 8-slot table (<= 5 keys) / 32-slot table (py2compat.py)
     auto rank = [&](int a) {
-        const int r8[6] = {0, 5, 6, 2, 7, 4}, r32[6] = {0, 21, 6, 2, 15, 20};
-        return a < 6 ? (nkeys <= 5 ? r8[a] : r32[a]) : 64 + a;
+        return a < 6 ? (int)(((nkeys <= 5 ? 0x040702060500ull : 0x140F02061500ull) >> (8 * a)) & 0xffull) : 64 + a;
     };
+    // top two by (PI desc, rank asc): one pass (a strict total order, so this equals two argmax passes)
     int best = -1, second = -1;
-    for (int pass = 0; pass < 2; ++pass) {
-        int pick = -1;
-        double ppi = 0.0;
-        for (int a = 0; a < nA; ++a) {
-            if (!((touched >> a) & 1ull) || a == best) continue;
-            const double v = PI(a);
-            if (pick < 0 || v > ppi || (v == ppi && rank(a) < rank(pick))) { pick = a; ppi = v; }
-        }
-        if (pass == 0) best = pick; else second = pick;
+    double vb = 0.0, vs = 0.0;
+    int rb = 0, rs = 0;
+    for (int a = 0; a < nA; ++a) {
+        if (!((touched >> a) & 1ull)) continue;
+        const double v = PI(a);
+        const int r = rank(a);
+        if (best < 0 || v > vb || (v == vb && r < rb)) { second = best; vs = vb; rs = rb; best = a; vb = v; rb = r; }
+        else if (second < 0 || v > vs || (v == vs && r < rs)) { second = a; vs = v; rs = r; }
     }
     R->status = downsampled ? SMC_ST_DOWNSAMPLED : SMC_ST_OK;
     R->n_touched = nkeys;
@@ -313,38 +316,42 @@ __device__ __forceinline__ void finish_row(smc_row* R, const smc_locus& L, int l
     R->mt3 = misc[M_MT3]; R->mt5 = misc[M_MT5]; R->mt7 = misc[M_MT7]; R->mt10 = misc[M_MT10];
     R->max_allele = best; R->second_allele = second;
     R->touched_mask = touched;
-    for (int k = 0; k < 4; ++k) {
+    for (int k = lane; k < 4; k += step) {
         R->dp[k] = tal[k * SMC_NT + SMC_T_CNT];
         R->umt[k] = mtc[k];
         R->vsm[k] = strong[k];
         R->pi[k] = PI(k);
     }
     const int ref = L.ref_allele;
-    if (ref < nA) for (int k = 0; k < SMC_NT; ++k) R->ref_tal[k] = tal[ref * SMC_NT + k];
-    auto fill = [&](smc_cand& C, int a) {
+    if (ref < nA) for (int k = lane; k < SMC_NT; k += step) R->ref_tal[k] = tal[ref * SMC_NT + k];
+    auto fill = [&](smc_cand& C, int a, double pia) {
         C.allele = a;
         C.p_sb = C.p_r1 = C.p_r2 = C.p_pr = NAN;
         if (a < 0) return;
-        C.pi = PI(a);
+        C.pi = pia;
         C.vdp = tal[a * SMC_NT + SMC_T_CNT];
         C.vmt = mtc[a];
         C.vsm = strong[a];
-        for (int k = 0; k < SMC_NT; ++k) C.tal[k] = tal[a * SMC_NT + k];
+        for (int k = lane; k < SMC_NT; k += step) C.tal[k] = tal[a * SMC_NT + k];
     };
     auto filterable = [&](int a) { return ((L.snp_mask >> a) & 1ull) || a != GAP_ID; };  // SNP or INDEL
     const int alt = best == ref ? second : best;                                   // :541
-    fill(R->cand[0], alt);
-    if (alt >= 0 && R->cand[0].pi >= 5 && filterable(alt)) R->cand[0].flt_applied = 1;   // :549
+    const double pi_alt = best == ref ? vs : vb;
+    fill(R->cand[0], alt, pi_alt);
+    const bool flt0 = alt >= 0 && pi_alt >= 5 && filterable(alt);                 // :549
+    bool flt1 = false;
+    if (flt0) R->cand[0].flt_applied = 1;
     if (best >= 0 && second >= 0 && best != ref && second != ref && 1.0 * mtc[best] / used >= 0.45 &&
         1.0 * mtc[second] / used >= 0.45) {                                        // :553-555
         R->biallelic = 1;
-        fill(R->cand[1], second);
-        if (R->cand[1].pi >= 5 && filterable(second)) R->cand[1].flt_applied = 1;   // :563
+        fill(R->cand[1], second, vs);
+        flt1 = vs >= 5 && filterable(second);                                      // :563
+        if (flt1) R->cand[1].flt_applied = 1;
     } else {
-        fill(R->cand[1], -1);
+        fill(R->cand[1], -1, 0.0);
     }
     // loci whose candidate(s) go through filterVariants are queued for k_filter_loci
-    if (R->cand[0].flt_applied || R->cand[1].flt_applied) flt_list[1 + atomicAdd(&flt_list[0], 1u)] = (uint32_t)li;
+    if ((flt0 || flt1) && lane == 0) flt_list[1 + atomicAdd(&flt_list[0], 1u)] = (uint32_t)li;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1122,11 +1129,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         // ---- E: ranking and candidates (:534-555), one thread; the row is staged over the (dead) LUT
         for (int i = tid; i < (int)(sizeof(smc_row) / 4); i += BLOCK) ((uint32_t*)rowst)[i] = 0u;
         __syncthreads();
-        if (tid == 0)
-        {
+        if (wid == 0) {                                                 // the first wavefront, every lane
             const int n_bc = (int)H->misc[M_NBC];
             finish_row(rowst, L, li, n, nF, n_bc < P.ds ? n_bc : P.ds /* usedMT, :489 */, n_bc > P.ds, fxscale, H->misc, tal,
-                       pifx, mtc, strong, flt_list);
+                       pifx, mtc, strong, flt_list, lane, WAVE);
         }
         __syncthreads();
         const uint32_t* src = (const uint32_t*)rowst;
@@ -1600,7 +1606,7 @@ __global__ __launch_bounds__(WAVE) void k_call_sorted(
                 R->cand[c].p_sb = R->cand[c].p_r1 = R->cand[c].p_r2 = R->cand[c].p_pr = NAN;
             }
         } else {
-            finish_row(R, L, li, n, nF, used, (int)n_bc > P.ds, fxscale, H->misc, tal, pifx, mtc, strong, flt_list);
+            finish_row(R, L, li, n, nF, used, (int)n_bc > P.ds, fxscale, H->misc, tal, pifx, mtc, strong, flt_list, 0, 1);
         }
     }
     __syncthreads();
