@@ -595,13 +595,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
     // ---- R: mate merge (smCounter.py:468-479), assuming every fragment has <= 2 included reads;
     // the count of reads so explained is checked against the number of included reads below.
     auto resolve = [&](bool honour_marks) {
-        uint32_t c = 0, conc_ref = 0, disc_ref = 0;                      // c is wave-uniform
+        uint32_t c = 0, conc_ref = 0, disc_ref = 0;                      // wave-uniform counts
         const uint32_t refa = L.ref_allele;
-        for (int sb = 0; sb < nF; sb += BLOCK) {
-            const int s = sb + tid;
-            const lmask m_in = BAL(s < nF);
-            uint32_t a = 0xFFFFFFFFu, b = 0u;
-            if (LANES(m_in)) { a = fmin[s]; b = fmax[s]; }
+        // one chunk of 64 slots per wavefront: classify, write the state word, leave the chunk masks
+        auto chunk = [&](int s, lmask m_in, uint32_t a, uint32_t b) {
             const lmask m_marked = honour_marks ? (m_in & BAL(b == 0xFFFFFFFFu)) : 0ull;
             const lmask m_has = m_in & ~m_marked & BAL(a != 0xFFFFFFFFu);
             const lmask m_single = m_has & BAL(a == b), m_pair = m_has & ~m_single;
@@ -623,16 +620,24 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                 cmask[2 * (s >> 6) + 1] = m_live & m_a1ref;
             }
             const lmask c_ref = m_conc & m_a1ref, d_ref = m_disc & BAL(a2 == refa);
-            ADDM(conc_ref, c_ref);
-            ADDM(disc_ref, d_ref);
+            conc_ref += (uint32_t)__popcll(c_ref);
+            disc_ref += (uint32_t)__popcll(d_ref);
             const lmask rare = (m_conc & ~c_ref) | (m_disc & ~d_ref);
             if (rare) {
                 if (LANES(m_conc & ~c_ref)) atomicAdd(&tal[a1 * SMC_NT + SMC_T_CONCORD], 1u);
                 if (LANES(m_disc & ~d_ref)) atomicAdd(&tal[a2 * SMC_NT + SMC_T_DISCORD], 1u);
             }
+        };
+        // two chunks per step, their four LDS reads issued together
+        for (int sb = 0; sb < nF; sb += 2 * BLOCK) {
+            const int s0 = sb + tid, s1 = s0 + BLOCK;
+            const lmask in0 = BAL(s0 < nF), in1 = BAL(s1 < nF);
+            uint32_t a0 = 0xFFFFFFFFu, b0 = 0u, a1 = 0xFFFFFFFFu, b1 = 0u;
+            if (LANES(in0)) { a0 = fmin[s0]; b0 = fmax[s0]; }
+            if (LANES(in1)) { a1 = fmin[s1]; b1 = fmax[s1]; }
+            chunk(s0, in0, a0, b0);
+            if (in1) chunk(s1, in1, a1, b1);
         }
-        conc_ref = (uint32_t)wave_add((int)conc_ref);
-        disc_ref = (uint32_t)wave_add((int)disc_ref);
         if (lane == 0 && refa < (uint32_t)nA) {
             if (conc_ref) atomicAdd(&tal[refa * SMC_NT + SMC_T_CONCORD], conc_ref);
             if (disc_ref) atomicAdd(&tal[refa * SMC_NT + SMC_T_DISCORD], disc_ref);
