@@ -416,6 +416,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         lut_reg[t] = i < LUT_N ? g_lut[i] : 0.0;
     }
     // ---- S0: init
+    uint32_t b0_early = 0xFFFFFFFFu;
     {
         uint32_t* z = (uint32_t*)smem;
         const int nz = (int)((sizeof(Hdr) + a_cap * 64) / 4);
@@ -424,6 +425,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         // first read of every barcode (+ closing entry); S2 turns it into the first fragment slot
         const uint32_t* ustart = g_umi_start + L.umi_off;
         for (int i = tid; i <= nU; i += BLOCK) umi_base[i] = ustart[i];
+        // one barcode per thread at most: its first slot (= slot of its first read) is fetched now and rides in
+        // a register through the scan - the scan streams the same lines right after, so they are fetched from
+        // HBM once (a gather after the scan finds them evicted: + 10 % traffic)
+        if (nU <= BLOCK && tid < nU) {
+            const uint32_t r0 = ustart[tid];
+            b0_early = r0 < (uint32_t)n ? (g_frag + 4ll * L.read_off4)[r0] : 0xFFFFFFFFu;
+        }
     }
     __syncthreads();
     STAMP(0);
@@ -550,7 +558,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
             if (u < nU) {
                 const uint32_t r0 = umi_base[u], r1 = umi_base[u + 1];
                 bad |= !(r0 < r1 && r1 <= (uint32_t)n) || (u == 0 && r0 != 0) || (u == nU - 1 && r1 != (uint32_t)n);
-                b0 = r0 < (uint32_t)n ? frag[r0] : 0xFFFFFFFFu;
+                b0 = nU <= BLOCK ? b0_early : (r0 < (uint32_t)n ? frag[r0] : 0xFFFFFFFFu);
             }
             __syncthreads();                                            // every r1 of this step is read
             if (u < nU) umi_base[u] = b0;
