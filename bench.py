@@ -156,6 +156,7 @@ def main():
         }
         if cpu is not None:
             out["cpu_baseline"], out["cpu_baseline_c"] = cpu["python_pool"], cpu["c_port"]
+            out["cpu_baseline_c_all_cores"] = cpu["c_port_all_cores"]
             gpu_rows = plan.download(rows)[:len(cpu["rows"])]
             bad = abi.compare_rows(gpu_rows, cpu["rows"], fragile=cpu["fragile"])
             out["parity_sample"] = {"loci": len(gpu_rows), "mismatches": len(bad), "detail": bad[:3]}
@@ -170,7 +171,8 @@ def cpu_leg(a):
     * python_pool - oracle/vc_port.py, the pure-Python restatement of vc(), driven like the reference's
       main(): multiprocessing.Pool(all host cores), one task per locus, on the first 2000 loci;
     * c_port - oracle/smc_oracle.c on one core over the whole first chunk; its rows are kept to check
-      the GPU rows of that chunk field by field after the timed run."""
+      the GPU rows of that chunk field by field after the timed run;
+    * c_port_all_cores - the same C code on every host core (threads over contiguous locus ranges)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_lib
     import vc_port
@@ -183,6 +185,12 @@ def cpu_leg(a):
     ref_rows, fragile = oracle_lib.call_batch(sample, abi.c_params(params), abi.ROW_DTYPE, return_fragile=True)
     dt_c = time.perf_counter() - t
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    reps = 5
+    t = time.perf_counter()
+    for _ in range(reps):
+        mt_rows = oracle_lib.call_batch_mt(sample, abi.c_params(params), abi.ROW_DTYPE, cores)
+    dt_cmt = (time.perf_counter() - t) / reps
+    assert mt_rows.tobytes() == ref_rows.tobytes()
     n_py = min(n, max(2000, 40 * cores))
     pool = vc_port.make_pool(cores)                 # started and warmed outside the timed region
     t = time.perf_counter()
@@ -197,6 +205,9 @@ def cpu_leg(a):
                                   % (n_py, cores, dt_py)},
         "c_port": {"value": n / dt_c, "unit": "loci/s", "cores": 1, "kind": "port",
                    "sample": "first %d loci, C restatement oracle/smc_oracle.c, 1 thread, %.1f s" % (n, dt_c)},
+        "c_port_all_cores": {"value": n / dt_cmt, "unit": "loci/s", "cores": cores, "kind": "port",
+                             "sample": "first %d loci, C restatement oracle/smc_oracle.c on %d threads (contiguous locus "
+                                       "ranges), mean of %d passes, %.3f s each" % (n, cores, reps, dt_cmt)},
         "rows": ref_rows, "fragile": fragile}
 
 

@@ -60,6 +60,36 @@ def call_batch(db, cparams, row_dtype, return_fragile=False):
     return rows
 
 
+def call_batch_mt(db, cparams, row_dtype, n_threads):
+    """The same C restatement over contiguous locus ranges on n_threads host threads (ctypes releases the
+    GIL during the call; the library keeps no state).  Used by bench.py for the all-cores C baseline."""
+    import threading
+    L = lib()
+    rows = np.zeros(db.n_loci, row_dtype)
+    loci = np.ascontiguousarray(db.loci)
+    bounds = [db.n_loci * t // n_threads for t in range(n_threads + 1)]
+    errs = []
+
+    def work(lo, hi):
+        if hi <= lo:
+            return
+        rc = L.smc_oracle_call_batch(ctypes.byref(cparams),
+                                     ctypes.c_void_p(loci.ctypes.data + lo * loci.dtype.itemsize), ctypes.c_int64(hi - lo),
+                                     db.meta.ctypes.data_as(ctypes.c_void_p), db.umi.ctypes.data_as(ctypes.c_void_p),
+                                     db.frag.ctypes.data_as(ctypes.c_void_p), db.dist.ctypes.data_as(ctypes.c_void_p),
+                                     ctypes.c_void_p(rows.ctypes.data + lo * row_dtype.itemsize))
+        if rc != 0:
+            errs.append(rc)
+    th = [threading.Thread(target=work, args=(bounds[t], bounds[t + 1])) for t in range(n_threads)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if errs:
+        raise RuntimeError("smc_oracle_call_batch failed: %r" % errs)
+    return rows
+
+
 def fisher(a, b, c, d):
     o, p = ctypes.c_double(), ctypes.c_double()
     lib().smc_oracle_fisher(ctypes.c_int64(a), ctypes.c_int64(b), ctypes.c_int64(c), ctypes.c_int64(d),

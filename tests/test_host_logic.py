@@ -164,3 +164,14 @@ def test_no_gpu_fails_loudly():
     from smcounter_amd import engine
     with pytest.raises(_lib.SmcError):
         engine.Engine(0)
+
+
+def test_oracle_multithread_wrapper_matches_single_thread():
+    import oracle_lib
+    from smcounter_amd import synth, abi
+    cfg = synth.CONFIGS["C2"]
+    P = synth.params_for(cfg)
+    db = synth.generate_native(cfg, 0, 300, P)
+    a = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE)
+    b = oracle_lib.call_batch_mt(db, abi.c_params(P), abi.ROW_DTYPE, 5)
+    assert a.tobytes() == b.tobytes()
