@@ -91,6 +91,12 @@ typedef struct smc_params {
  * SMC_ST_BAD_INPUT: frag < n_frag, allele < n_alleles, umi_start ascending and covering [0, n_reads),
  * barcode slot ranges ascending and covering [0, n_frag).
  * Base qualities are Phred values <= 126 (BAM holds 0..93); larger bytes are clamped to 126. */
+/* smc_locus.flags */
+#define SMC_LF_SAMPLED 1u /* the host has applied the reference's down-sampling (smCounter.py:496-498): barcodes whose
+                           * umi_start entry has bit 31 set are keys of bcDict the sample dropped; the number kept must be
+                           * min(#keys, ds), else the row is SMC_ST_BAD_INPUT. Without this flag a locus over the cap gets
+                           * the non-parity stand-in (ds lowest barcode ids). */
+#define SMC_USTART_DROPPED 0x80000000u
 typedef struct smc_locus {
     uint32_t read_off4; /* first plane slot / 4 */
     uint32_t umi_off;   /* first entry of this locus in the umi_start array */

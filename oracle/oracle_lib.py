@@ -24,40 +24,27 @@ def lib():
             build()
         _LIB = ctypes.CDLL(path)
         _LIB.smc_oracle_call_batch.restype = ctypes.c_int
+        _LIB.smc_oracle_call_batch_ds.restype = ctypes.c_int
         _LIB.smc_oracle_fisher.restype = None
     return _LIB
 
 
 def call_batch(db, cparams, row_dtype, return_fragile=False):
     """db: smcounter_amd.features.DeviceBatch; cparams: ctypes smc_params; -> structured rows
-    (and, on request, the per-locus count of barcodes whose consensus hinges on rounding)."""
+    (and, on request, the per-locus count of barcodes whose consensus hinges on rounding).  The batch's
+    umi_start is passed along: it carries the host's down-sampling marks (SMC_LF_SAMPLED loci)."""
     L = lib()
     assert L.smc_oracle_row_size() == row_dtype.itemsize
     rows = np.zeros(db.n_loci, row_dtype)
     loci = np.ascontiguousarray(db.loci)
-    if return_fragile:
-        fragile = np.zeros(db.n_loci, np.int32)
-        rc = L.smc_oracle_call_batch_ex(ctypes.byref(cparams), loci.ctypes.data_as(ctypes.c_void_p),
-                                        ctypes.c_int64(db.n_loci),
-                                        db.meta.ctypes.data_as(ctypes.c_void_p),
-                                        db.umi.ctypes.data_as(ctypes.c_void_p),
-                                        db.frag.ctypes.data_as(ctypes.c_void_p),
-                                        db.dist.ctypes.data_as(ctypes.c_void_p),
-                                        rows.ctypes.data_as(ctypes.c_void_p),
-                                        fragile.ctypes.data_as(ctypes.c_void_p))
-        if rc != 0:
-            raise RuntimeError("smc_oracle_call_batch_ex failed: %d" % rc)
-        return rows, fragile
-    rc = L.smc_oracle_call_batch(ctypes.byref(cparams), loci.ctypes.data_as(ctypes.c_void_p),
-                                 ctypes.c_int64(db.n_loci),
-                                 db.meta.ctypes.data_as(ctypes.c_void_p),
-                                 db.umi.ctypes.data_as(ctypes.c_void_p),
-                                 db.frag.ctypes.data_as(ctypes.c_void_p),
-                                 db.dist.ctypes.data_as(ctypes.c_void_p),
-                                 rows.ctypes.data_as(ctypes.c_void_p))
+    fragile = np.zeros(db.n_loci, np.int32)
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rc = L.smc_oracle_call_batch_ds(ctypes.byref(cparams), ptr(loci), ctypes.c_int64(db.n_loci), ptr(db.meta), ptr(db.umi),
+                                    ptr(db.frag), ptr(db.dist), ptr(np.ascontiguousarray(db.umi_start)), ptr(rows),
+                                    ptr(fragile))
     if rc != 0:
-        raise RuntimeError("smc_oracle_call_batch failed: %d" % rc)
-    return rows
+        raise RuntimeError("smc_oracle_call_batch_ds failed: %d" % rc)
+    return (rows, fragile) if return_fragile else rows
 
 
 def call_batch_mt(db, cparams, row_dtype, n_threads):

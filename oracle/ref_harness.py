@@ -45,6 +45,7 @@ class _Capture(object):
         self.fisher = []     # (table, oddsratio, pvalue)
         self.calprob = []    # per-UMI posterior dicts, in bcKeys order
         self.final = []      # finalDict.items() as handed to sorted() (smCounter.py:534)
+        self.sampled = False # random.sample ran (smCounter.py:497-498)
 
 
 CAP = _Capture()
@@ -103,6 +104,25 @@ def load_reference():
         return out
 
     mod.__dict__["calProb"] = cal
+
+    # random.seed(pos) / random.sample(bcDict.keys(), ds) (smCounter.py:496-498) as CPython 2.7 computes them:
+    # the py3 dict hands the keys over in insertion order; py2 would iterate them in hash-slot order and draw
+    # with int(random() * n) from a generator seeded with the 64-bit string hash (py2compat.Py2Random)
+    class _Py2RandomModule(object):
+        def __init__(self):
+            self._r = None
+
+        def seed(self, a):
+            self._r = py2compat.Py2Random(a)
+
+        def sample(self, population, k):
+            CAP.sampled = True
+            return self._r.sample(py2compat.py2_dict_order(list(population)), k)
+
+        def random(self):
+            return self._r.random()
+
+    mod.__dict__["random"] = _Py2RandomModule()
     return mod
 
 
@@ -134,7 +154,8 @@ def locus_to_stub_reads(pb, l):
         cigar.append((0, max(1, body - body // 2)))
         fl = int(pb.flag[i])
         out.append(dict(
-            qname="f%d_%d:NN:U%d:x" % (int(pb.umi[i]), int(pb.frag[i]), int(pb.umi[i])),
+            qname="f%d_%d:NN:%s:x" % (int(pb.umi[i]), int(pb.frag[i]),
+                                      pb.umi_names[l][int(pb.umi[i])] if pb.umi_names is not None else "U%d" % int(pb.umi[i])),
             mq=int(pb.mq[i]), nm=int(pb.nm[i]), has_nm=bool(fl & F_HAS_NM), cigar=cigar,
             qlen=qlen, qalen=int(pb.qalen[i]), is_read1=bool(fl & F_READ1),
             is_read2=bool(fl & F_READ2), is_reverse=bool(fl & F_REVERSE),
@@ -188,7 +209,8 @@ def run_reference(pb, params, chroms, use_wrapper=True):
                      params.mtDepth, params.rpb, params.hpLen, params.mismatchThr, params.mtDrop,
                      params.maxMT, params.primerDist, fa)
         res.append(dict(row=row, pi_raw=list(CAP.round2), fisher=list(CAP.fisher),
-                        n_umi_used=len(CAP.calprob), tie_ambiguous=_tie_ambiguous(CAP.final)))
+                        n_umi_used=len(CAP.calprob), tie_ambiguous=_tie_ambiguous(CAP.final),
+                        sampled=bool(CAP.sampled)))
     return res
 
 

@@ -144,7 +144,8 @@ static int tie_rank(int a, int n_keys) {
  * the iteration order of a dict (smCounter.py:62) - not pinned by the algorithm, so parity tests
  * skip the MT-count columns of the few loci that contain one. */
 static int call_locus(const smc_params* P, const smc_locus* L, const uint32_t* meta, const uint32_t* umi,
-                      const uint32_t* frag, const uint32_t* dist, smc_row* R, int32_t* fragile) {
+                      const uint32_t* frag, const uint32_t* dist, const uint32_t* ustart /* may be NULL */, smc_row* R,
+                      int32_t* fragile) {
     if (fragile) *fragile = 0;
     memset(R, 0, sizeof *R);
     R->max_allele = R->second_allele = -1;
@@ -235,9 +236,25 @@ static int call_locus(const smc_params* P, const smc_locus* L, const uint32_t* m
         free(nfrag); free(foff); free(in_bc); free(bc_order); free(ft);
         return 0;
     }
-    if (n_bc > P->ds) {
-        /* the reference would random.sample() here (:496-498); parity mode never reaches this.
-         * Deterministic stand-in shared with the device path: keep the ds lowest barcode ids. */
+    if ((L->flags & SMC_LF_SAMPLED) && ustart) {
+        /* random.sample() of the reference (:496-498) was applied by the host (features.py, py2compat.py):
+         * keys of bcDict marked in umi_start are dropped; the count kept must be min(#keys, ds) */
+        int k = 0;
+        for (int u = 0; u < nU; ++u)
+            if (in_bc[u] && !(ustart[u] & SMC_USTART_DROPPED)) { if (k < n_bc) bc_order[k] = u; ++k; }
+        if (k != used) {
+            memset(R, 0, sizeof *R);
+            R->max_allele = R->second_allele = -1;
+            fill_cand(&R->cand[0], -1, 0, NULL, NULL, NULL);
+            fill_cand(&R->cand[1], -1, 0, NULL, NULL, NULL);
+            R->status = SMC_ST_BAD_INPUT;
+            free(nfrag); free(foff); free(in_bc); free(bc_order); free(ft);
+            return 0;
+        }
+        if (n_bc > P->ds) R->status |= SMC_ST_DOWNSAMPLED;
+    } else if (n_bc > P->ds) {
+        /* no host sample: deterministic stand-in shared with the device path (non-parity): keep the ds
+         * lowest barcode ids */
         R->status |= SMC_ST_DOWNSAMPLED;
         int k = 0;
         for (int u = 0; u < nU && k < used; ++u) if (in_bc[u]) bc_order[k++] = u;
@@ -361,27 +378,27 @@ static int call_locus(const smc_params* P, const smc_locus* L, const uint32_t* m
     return 0;
 }
 
-int smc_oracle_call_batch(const smc_params* P, const smc_locus* loci, int64_t n_loci, const uint32_t* meta,
-                          const uint32_t* umi, const uint32_t* frag, const uint32_t* dist, smc_row* rows) {
+/* umi_start may be NULL (no host-applied down-sampling marks); otherwise the array of include/smcounter_hip.h */
+int smc_oracle_call_batch_ds(const smc_params* P, const smc_locus* loci, int64_t n_loci, const uint32_t* meta,
+                             const uint32_t* umi, const uint32_t* frag, const uint32_t* dist, const uint32_t* umi_start,
+                             smc_row* rows, int32_t* fragile) {
     for (int64_t l = 0; l < n_loci; ++l) {
         const smc_locus* L = &loci[l];
         if (L->n_alleles > SMC_MAX_ALLELES) return -1;
         call_locus(P, L, meta + 4 * (int64_t)L->read_off4, umi + 4 * (int64_t)L->read_off4, frag + 4 * (int64_t)L->read_off4,
-                   dist + 4 * (int64_t)L->read_off4, &rows[l], NULL);
+                   dist + 4 * (int64_t)L->read_off4, umi_start ? umi_start + L->umi_off : NULL, &rows[l],
+                   fragile ? &fragile[l] : NULL);
     }
     return 0;
 }
-
+int smc_oracle_call_batch(const smc_params* P, const smc_locus* loci, int64_t n_loci, const uint32_t* meta,
+                          const uint32_t* umi, const uint32_t* frag, const uint32_t* dist, smc_row* rows) {
+    return smc_oracle_call_batch_ds(P, loci, n_loci, meta, umi, frag, dist, NULL, rows, NULL);
+}
 int smc_oracle_call_batch_ex(const smc_params* P, const smc_locus* loci, int64_t n_loci, const uint32_t* meta,
                              const uint32_t* umi, const uint32_t* frag, const uint32_t* dist, smc_row* rows,
                              int32_t* fragile) {
-    for (int64_t l = 0; l < n_loci; ++l) {
-        const smc_locus* L = &loci[l];
-        if (L->n_alleles > SMC_MAX_ALLELES) return -1;
-        call_locus(P, L, meta + 4 * (int64_t)L->read_off4, umi + 4 * (int64_t)L->read_off4, frag + 4 * (int64_t)L->read_off4,
-                   dist + 4 * (int64_t)L->read_off4, &rows[l], fragile ? &fragile[l] : NULL);
-    }
-    return 0;
+    return smc_oracle_call_batch_ds(P, loci, n_loci, meta, umi, frag, dist, NULL, rows, fragile);
 }
 
 /* exposed for tests: the Fisher restatement against captured scipy calls */

@@ -105,7 +105,7 @@ def _filters(alt, ref, snp_mask, used, tal, mtcnt, strong, cvg):
     return f, int(vmf), (p_sb, p_r1, p_r2, p_pr)
 
 
-def vc_locus(meta, umi, frag, dist, ref, n_alleles, snp_mask, min_bq, min_mq, mt_drop, primer_dist, ds, smt):
+def vc_locus(meta, umi, frag, dist, ref, n_alleles, snp_mask, min_bq, min_mq, mt_drop, primer_dist, ds, smt, dropped=None):
     """One locus.  Arrays are the device planes restricted to the locus (see smcounter_amd/features.py)."""
     tal = defaultdict(lambda: [0] * 11)
     bc = {}                      # barcode -> {slot: [allele, prob, paired]}  (bcDict, insertion-ordered)
@@ -158,7 +158,12 @@ def vc_locus(meta, umi, frag, dist, ref, n_alleles, snp_mask, min_bq, min_mq, mt
     keys = list(bc.keys())
     if len(bc) > ds:
         row["status"] |= 0x100
-        keys = sorted(keys)[:ds]
+        if dropped is not None:
+            # the reference's random.sample (smCounter.py:496-498), run by the host (features.py / py2compat.py)
+            keys = [u for u in keys if u not in dropped]
+            assert len(keys) == used
+        else:
+            keys = sorted(keys)[:ds]        # documented non-parity stand-in
     fin = defaultdict(float)
     mtcnt, strong = defaultdict(int), defaultdict(int)
     mt = [0, 0, 0, 0]
@@ -229,9 +234,13 @@ def call_batch(db, params, n_cpu=1, loci=None, pool=None):
     for l in idx:
         L = db.loci[l]
         o, n = 4 * int(L["read_off4"]), int(L["n_reads"])
+        dropped = None
+        if int(L["flags"]) & 1:
+            us = db.umi_start[int(L["umi_off"]):int(L["umi_off"]) + int(L["n_umi"])]
+            dropped = set(np.nonzero(us >> 31)[0].tolist())
         tasks.append((db.meta[o:o + n], db.umi[o:o + n], db.frag[o:o + n], db.dist[o:o + n], int(L["ref_allele"]),
                       int(L["n_alleles"]), int(L["snp_mask"]), params.minBQ, params.minMQ, params.mtDrop,
-                      params.primerDist, params.ds, params.smt))
+                      params.primerDist, params.ds, params.smt, dropped))
     if n_cpu <= 1 and pool is None:
         return [vc_locus(*t) for t in tasks]
     own = pool is None

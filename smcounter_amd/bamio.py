@@ -332,6 +332,7 @@ class _LocusBuilder(object):
         self.cols = {k: [] for k in ("umi", "frag", "flag", "mq", "nm", "n_indel", "left_sp", "qlen", "qalen",
                                      "qpos", "indel", "is_del", "allele", "bq")}
         self.chrom, self.pos, self.ref, self.alleles, self.off = [], [], [], [], [0]
+        self.umi_names = []
 
     def add_locus(self, chrom: str, pos1: int, reads: List[Alignment], fasta):
         pos0 = pos1 - 1
@@ -393,6 +394,7 @@ class _LocusBuilder(object):
         self.pos.append(pos1)
         self.ref.append(fasta.fetch(chrom, pos0, pos1).upper())
         self.alleles.append(table)
+        self.umi_names.append(list(umis))          # barcode texts by dense id (for the py2 down-sampling)
         self.off.append(self.off[-1] + n)
 
     def build(self) -> PileupBatch:
@@ -400,7 +402,7 @@ class _LocusBuilder(object):
                   left_sp=np.uint32, qlen=np.uint32, qalen=np.uint32, qpos=np.int32, indel=np.int32,
                   is_del=bool, allele=np.uint8, bq=np.uint8)
         return PileupBatch(chrom=self.chrom, pos=np.array(self.pos, np.int64), ref=self.ref,
-                           alleles=self.alleles, read_off=np.array(self.off, np.int64),
+                           alleles=self.alleles, read_off=np.array(self.off, np.int64), umi_names=self.umi_names,
                            **{k: np.array(v, dt[k]) for k, v in self.cols.items()})
 
 
@@ -461,7 +463,9 @@ def _native_lib():
         lib.smc_bam_keys_len.restype = C.c_int64
         lib.smc_bam_copy.argtypes = [C.c_void_p] * 18
         lib.smc_bam_planes.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int64, C.c_double,
-                                       C.c_char_p, C.c_int] + [C.POINTER(C.c_int64)] * 3
+                                       C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.POINTER(C.c_int64)] * 3
+        lib.smc_bam_ds_info.argtypes = [C.c_void_p]
+        lib.smc_bam_ds_info.restype = C.c_char_p
         lib.smc_bam_planes.restype = C.c_int64
         lib.smc_bam_planes_copy.argtypes = [C.c_void_p] * 9
         _NATIVE = lib
@@ -529,16 +533,16 @@ class NativeBam(object):
                 k += int(n_keys[l])
         return tables
 
-    def planes_run(self, chrom: str, lo: int, hi: int, max_reads: int, mismatch_thr: float, refseq: str,
-                   nthreads: int, fasta):
+    def planes_run(self, chrom: str, lo: int, hi: int, max_reads: int, params, refseq: str, nthreads: int, fasta):
         """Fused decode + feature extraction of a run -> (n loci, 4 planes, umi_start, LOCUS_DTYPE array,
         allele tables); offsets in the descriptors are relative to this run."""
         import ctypes as C
         from .features import LOCUS_DTYPE, PileupError
         done, n_slots, n_us = C.c_int64(0), C.c_int64(0), C.c_int64(0)
         refb = refseq.encode().ljust(hi - lo, b"\0")
-        n = self._lib.smc_bam_planes(self._h, chrom.encode(), lo, hi, max_reads, float(mismatch_thr), refb,
-                                     int(nthreads), C.byref(done), C.byref(n_slots), C.byref(n_us))
+        n = self._lib.smc_bam_planes(self._h, chrom.encode(), lo, hi, max_reads, float(params.mismatchThr), refb,
+                                     int(nthreads), int(params.ds), int(params.minBQ), int(params.minMQ),
+                                     C.byref(done), C.byref(n_slots), C.byref(n_us))
         if n < 0:
             msg = self._lib.smc_bam_error(self._h).decode()
             raise (PileupError if n <= -6 else BamError)(msg)
@@ -551,6 +555,21 @@ class NativeBam(object):
         ptr = lambda a: a.ctypes.data_as(C.c_void_p)
         self._lib.smc_bam_planes_copy(self._h, *[ptr(p) for p in planes], ptr(ustart), ptr(loci), ptr(n_keys),
                                       C.cast(keys, C.c_void_p))
+        # the reference's down-sampling (smCounter.py:496-498) on loci over the barcode cap
+        info = self._lib.smc_bam_ds_info(self._h).decode()
+        if info:
+            from .features import LF_SAMPLED, USTART_DROPPED
+            from .py2compat import py2_downsample_barcodes
+            for line in info.splitlines():
+                parts = line.split("\t")
+                l = int(parts[0])
+                ids, names = zip(*[(int(x.split(":", 1)[0]), x.split(":", 1)[1]) for x in parts[1:]])
+                kept = set(py2_downsample_barcodes(str(lo + l + 1), list(names), params.ds))
+                o = int(loci["umi_off"][l])
+                for u, name in zip(ids, names):
+                    if name not in kept:
+                        ustart[o + u] |= USTART_DROPPED
+                loci["flags"][l] |= LF_SAMPLED
         return nl, planes, ustart, loci, self._tables(nl, n_keys, keys, chrom, lo, fasta)
 
 
@@ -606,8 +625,7 @@ def iter_device_batches_native(path: str, fasta, loci: Sequence[Tuple[str, str]]
                 j += 1
             lo, hi = int(loci[i][1]) - 1, int(loci[j][1])
             run_ref = fasta.fetch(chrom, lo, hi).upper()
-            nl, planes, ustart, lc, tb = bam.planes_run(chrom, lo, hi, max_reads - total, params.mismatchThr,
-                                                        run_ref, nthreads, fasta)
+            nl, planes, ustart, lc, tb = bam.planes_run(chrom, lo, hi, max_reads - total, params, run_ref, nthreads, fasta)
             lc["read_off4"] += slots // 4
             lc["umi_off"] += n_us
             for k in range(4):

@@ -59,6 +59,7 @@ struct Bam {
     // last smc_bam_planes result (keys / n_keys shared with the pileup result)
     std::vector<uint32_t> p_meta, p_umi, p_frag, p_dist, p_umi_start;
     std::vector<smc_locus> p_loci;
+    std::string ds_info;               // loci over the barcode cap: "<locus>\t<u>:<barcode>\t...\n", barcodes by first included read
 
     bool load_block(uint64_t coff) {
         if (fseeko(fh, (off_t)coff, SEEK_SET) != 0) return false;
@@ -169,7 +170,8 @@ bool parse_record(Bam& b, Aln& a, int32_t& tid) {
 
 // Mapped alignments overlapping [start0, end0) on `chrom`, in file order, with run-wide barcode / fragment ids
 // and the per-read CIGAR summaries.  Returns 0, or the negative error code of smc_bam_pileup.
-int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::vector<Aln>& reads, int& n_bc, int& n_pair) {
+int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::vector<Aln>& reads, int& n_bc, int& n_pair,
+                  std::vector<std::string>* bc_names = nullptr) {
     int tid = -1;
     for (size_t i = 0; i < b.ref_names.size(); ++i) if (b.ref_names[i] == chrom) tid = (int)i;
     std::unordered_map<std::string, int> bc_ids, pair_ids;
@@ -209,6 +211,7 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::
         }
     }
     n_bc = (int)bc_ids.size(); n_pair = (int)pair_ids.size();
+    if (bc_names) { bc_names->assign(bc_ids.size(), std::string()); for (const auto& kv : bc_ids) (*bc_names)[(size_t)kv.second] = kv.first; }
     return 0;
 }
 
@@ -376,6 +379,7 @@ int64_t smc_bam_pileup(void* h, const char* chrom, int64_t start0, int64_t end0,
 }
 
 int64_t smc_bam_keys_len(void* h) { return (int64_t)((Bam*)h)->keys.size(); }
+const char* smc_bam_ds_info(void* h) { return ((Bam*)h)->ds_info.c_str(); }
 
 // copy the last pileup into caller-owned arrays (sizes from smc_bam_pileup / n loci = end0 - start0)
 void smc_bam_copy(void* h, uint32_t* umi, uint32_t* frag, uint8_t* flag, uint8_t* mq, uint32_t* nm, uint32_t* n_indel,
@@ -403,15 +407,20 @@ void smc_bam_copy(void* h, uint32_t* umi, uint32_t* frag, uint8_t* flag, uint8_t
 // refseq: the upper-cased reference letters of [start0, end0).  Loci are processed by `nthreads` threads.
 // Returns pileup reads (unpadded), or < 0: -3/-4/-5 as smc_bam_pileup, -6 first read of a locus has neither
 // READ1 nor READ2, -7 base quality > 126, -8 more than 64 alleles at a locus.
+// ds > 0: for every locus with more barcodes than ds, the barcodes that own an included read (bq >= min_bq or inside a
+// deletion, mapq >= min_mq, mismatches within mismatch_thr: incCond, smCounter.py:378) are listed with their text in
+// order of that read (smc_bam_ds_info) - the host needs them for the reference's down-sampling (:496-498).
 int64_t smc_bam_planes(void* h, const char* chrom, int64_t start0, int64_t end0, int64_t max_reads, double mismatch_thr,
-                       const char* refseq, int nthreads, int64_t* n_loci_done, int64_t* n_slots, int64_t* n_umi_start) {
+                       const char* refseq, int nthreads, int ds, int min_bq, int min_mq, int64_t* n_loci_done,
+                       int64_t* n_slots, int64_t* n_umi_start) {
     Bam& b = *(Bam*)h;
-    b.keys.clear(); b.n_keys.clear();
+    b.keys.clear(); b.n_keys.clear(); b.ds_info.clear();
     *n_loci_done = *n_slots = *n_umi_start = 0;
     std::vector<Aln> reads;
     int n_bc = 0, n_pair = 0;
     const auto t_0 = std::chrono::steady_clock::now();
-    { const int rc = collect_reads(b, chrom, start0, end0, reads, n_bc, n_pair); if (rc) return rc; }
+    std::vector<std::string> bc_names;
+    { const int rc = collect_reads(b, chrom, start0, end0, reads, n_bc, n_pair, ds > 0 ? &bc_names : nullptr); if (rc) return rc; }
     const auto t_1 = std::chrono::steady_clock::now();
     // coverage per position: every read covers exactly [pos, end) (M/=/X/D/N are contiguous on the reference)
     const int64_t span = end0 - start0;
@@ -446,19 +455,21 @@ int64_t smc_bam_planes(void* h, const char* chrom, int64_t start0, int64_t end0,
         cut[(size_t)t] = std::max(cut[(size_t)t], cut[(size_t)t - 1]);
     }
     std::vector<std::vector<uint32_t>> t_ustart((size_t)T);
-    std::vector<std::string> t_keys((size_t)T);
+    std::vector<std::string> t_keys((size_t)T), t_ds((size_t)T);
     std::atomic<int> err(0);
     std::vector<std::string> t_err((size_t)T);
     auto work = [&](int t) {
         std::vector<int64_t> bc_stamp((size_t)n_bc, -1), pair_stamp((size_t)n_pair, -1);
         std::vector<int32_t> bc_local((size_t)n_bc), pair_local((size_t)n_pair), n_frag_of, n_reads_of, slot_base, slot_cnt;
         std::vector<uint32_t> c_meta, c_umi, c_frag, c_dist;
+        std::vector<int32_t> gid_of_u, inc_order;
+        std::vector<uint8_t> inc_seen;
         std::vector<std::string> extra;
         size_t w0 = 0;
         for (int64_t l = cut[(size_t)t]; l < cut[(size_t)t + 1] && !err.load(std::memory_order_relaxed); ++l) {
             const int64_t p0 = start0 + l;
             while (w0 < reads.size() && reads[w0].end <= p0) ++w0;
-            extra.clear(); n_frag_of.clear(); n_reads_of.clear();
+            extra.clear(); n_frag_of.clear(); n_reads_of.clear(); gid_of_u.clear(); inc_order.clear(); inc_seen.clear();
             c_meta.clear(); c_umi.clear(); c_frag.clear(); c_dist.clear();
             bool r2 = false, first = true;
             for (size_t ri = w0; ri < reads.size(); ++ri) {
@@ -470,7 +481,7 @@ int64_t smc_bam_planes(void* h, const char* chrom, int64_t start0, int64_t end0,
                 int u, f;
                 if (bc_stamp[(size_t)a.bc_gid] != p0) {
                     bc_stamp[(size_t)a.bc_gid] = p0; u = bc_local[(size_t)a.bc_gid] = (int)n_frag_of.size();
-                    n_frag_of.push_back(0); n_reads_of.push_back(0);
+                    n_frag_of.push_back(0); n_reads_of.push_back(0); gid_of_u.push_back(a.bc_gid); inc_seen.push_back(0);
                 } else u = bc_local[(size_t)a.bc_gid];
                 if (pair_stamp[(size_t)a.pair_gid] != p0) {
                     pair_stamp[(size_t)a.pair_gid] = p0; f = pair_local[(size_t)a.pair_gid] = n_frag_of[(size_t)u]++;
@@ -494,6 +505,9 @@ int64_t smc_bam_planes(void* h, const char* chrom, int64_t start0, int64_t end0,
                     const int64_t rel = (int64_t)qpos - (int64_t)a.left_sp, far = (int64_t)a.qalen - rel;
                     const int64_t dbc = r2 ? (rev ? rel : far) : (rev ? far : rel), dpr = r2 ? (rev ? far : rel) : 0;
                     dist = (uint32_t)std::min<int64_t>(65535, std::max<int64_t>(0, dbc)) | (uint32_t)std::min<int64_t>(65535, std::max<int64_t>(0, dpr)) << 16;
+                }
+                if (ds > 0 && !inc_seen[(size_t)u] && ((int)bq >= min_bq || kind == 1) && (int)a.mapq >= min_mq && (flags & 4u)) {
+                    inc_seen[(size_t)u] = 1; inc_order.push_back(u);
                 }
                 c_meta.push_back((uint32_t)ai | bq << 8 | flags << 16 | (uint32_t)a.mapq << 24);
                 c_umi.push_back((uint32_t)u); c_frag.push_back((uint32_t)f); c_dist.push_back(dist);
@@ -529,6 +543,12 @@ int64_t smc_bam_planes(void* h, const char* chrom, int64_t start0, int64_t end0,
             }
             L.ref_allele = (uint8_t)ra; L.n_alleles = (uint8_t)(6 + extra.size()); L.flags = 0; L.snp_mask = mask;
             b.n_keys[(size_t)l] = (int32_t)extra.size();
+            if (ds > 0 && (int)nu > ds && (int)inc_order.size() > ds) {
+                std::string& o = t_ds[(size_t)t];
+                o += std::to_string(l);
+                for (int32_t u : inc_order) { o += '\t'; o += std::to_string(u); o += ':'; o += bc_names[(size_t)gid_of_u[(size_t)u]]; }
+                o += '\n';
+            }
         }
     };
     if (T == 1) work(0);
@@ -545,6 +565,7 @@ int64_t smc_bam_planes(void* h, const char* chrom, int64_t start0, int64_t end0,
         for (int64_t l = cut[(size_t)t]; l < cut[(size_t)t + 1]; ++l) b.p_loci[(size_t)l].umi_off += base;
         b.p_umi_start.insert(b.p_umi_start.end(), t_ustart[(size_t)t].begin(), t_ustart[(size_t)t].end());
         b.keys += t_keys[(size_t)t];
+        b.ds_info += t_ds[(size_t)t];
     }
     *n_loci_done = nl; *n_slots = slots; *n_umi_start = (int64_t)b.p_umi_start.size();
     if (getenv("SMC_BAM_TIMING")) {

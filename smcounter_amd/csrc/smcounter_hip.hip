@@ -65,6 +65,7 @@ enum {
     M_CVG,
     M_NEEDFIX,
     M_NCOMPLEX,   // barcodes deferred to the general calProb path
+    M_NKEPT,      // bcDict keys the host's down-sampling kept (SMC_LF_SAMPLED loci)
 };
 
 #ifdef SMC_STAMPS
@@ -424,12 +425,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         for (int i = tid; i < nF; i += BLOCK) { fmin[i] = 0xFFFFFFFFu; fmax[i] = 0u; }
         // first read of every barcode (+ closing entry); S2 turns it into the first fragment slot
         const uint32_t* ustart = g_umi_start + L.umi_off;
-        for (int i = tid; i <= nU; i += BLOCK) umi_base[i] = ustart[i];
+        for (int i = tid; i <= nU; i += BLOCK) umi_base[i] = ustart[i] & ~SMC_USTART_DROPPED;
+        if (L.flags & SMC_LF_SAMPLED)                                  // the host's down-sampling marks, until U
+            for (int i = tid; i < nU; i += BLOCK) umi_flag[i] = (unsigned char)(ustart[i] >> 31);
         // one barcode per thread at most: its first slot (= slot of its first read) is fetched now and rides in
         // a register through the scan - the scan streams the same lines right after, so they are fetched from
         // HBM once (a gather after the scan finds them evicted: + 10 % traffic)
         if (nU <= BLOCK && tid < nU) {
-            const uint32_t r0 = ustart[tid];
+            const uint32_t r0 = ustart[tid] & ~SMC_USTART_DROPPED;
             b0_early = r0 < (uint32_t)n ? (g_frag + 4ll * L.read_off4)[r0] : 0xFFFFFFFFu;
         }
     }
@@ -576,7 +579,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
     __syncthreads();
     STAMP(2);
     smc_row* out = rows + li;
-    if (H->misc[M_ERR] || H->misc[M_NINC] == 0) {
+    if (H->misc[M_ERR] || H->misc[M_NINC] == 0 || P.ds <= 0) {          // (ds <= 0: usedMT = min(ds, .) = 0)
         // bad input, or no read enters bcDict: the Zero_Coverage row (smCounter.py:489-494)
         for (int i = tid; i < (int)(sizeof(smc_row) / 4); i += BLOCK) ((uint32_t*)rowst)[i] = 0u;
         __syncthreads();
@@ -823,19 +826,25 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         };
         // More barcodes than the cap can only happen when nU > ds: then a first pass finds bcDict's keys and the
         // down-sampling stand-in (non-parity; the reference random.samples, :496-498) keeps the ds lowest ids.
-        const bool two_pass = nU > P.ds;
+        // With SMC_LF_SAMPLED the host has run the reference's random.sample (py2compat.py) and marked the keys
+        // it dropped; the kept count is checked in E.
+        const bool sampled = (L.flags & SMC_LF_SAMPLED) != 0;
+        const bool two_pass = nU > P.ds || sampled;
         if (two_pass) {
-            uint32_t nb = 0;
+            uint32_t nb = 0, nkeep = 0;
             for (int u = tid; u < nU; u += BLOCK) {
                 int nf, cr; unsigned long long l1; uint32_t c1;
                 const bool key = barcode_counts(u, nf, cr, l1, c1);
-                umi_flag[u] = key;
+                const bool keep = key && !(sampled && umi_flag[u]);
+                umi_flag[u] = keep;
                 nb += key;
+                nkeep += keep;
             }
             nb = (uint32_t)wave_add((int)nb);
-            if (lane == 0 && nb) atomicAdd(&H->misc[M_NBC], nb);
+            nkeep = (uint32_t)wave_add((int)nkeep);
+            if (lane == 0 && nb) { atomicAdd(&H->misc[M_NBC], nb); atomicAdd(&H->misc[M_NKEPT], nkeep); }
             __syncthreads();
-            if ((int)H->misc[M_NBC] > P.ds) {
+            if (!sampled && (int)H->misc[M_NBC] > P.ds) {
                 if (tid == 0) {
                     int k = 0;
                     for (int u = 0; u < nU; ++u)
@@ -1146,6 +1155,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
             const int n_bc = (int)H->misc[M_NBC];
             finish_row(rowst, L, li, n, nF, n_bc < P.ds ? n_bc : P.ds /* usedMT, :489 */, n_bc > P.ds, fxscale, H->misc, tal,
                        pifx, mtc, strong, flt_list, lane, WAVE);
+            if (sampled && (int)H->misc[M_NKEPT] != (n_bc < P.ds ? n_bc : P.ds)) rowst->status = SMC_ST_BAD_INPUT;
         }
         __syncthreads();
         const uint32_t* src = (const uint32_t*)rowst;
@@ -1372,7 +1382,7 @@ __global__ __launch_bounds__(WAVE) void k_call_sorted(
         // ---- walk phase
         for (int t = g; t < nb; t += ngrp) {
             const int u = ub0 + t;
-            const uint32_t rb = ustart[u], re = ustart[u + 1];
+            const uint32_t rb = ustart[u] & ~SMC_USTART_DROPPED, re = ustart[u + 1] & ~SMC_USTART_DROPPED;
             if (!(rb < re && re <= (uint32_t)n) || (u == 0 && rb != 0)) { err_m |= 1; continue; }
             int nf = 0, cnt_ref = 0;
             unsigned long long mk = 0;
@@ -1578,7 +1588,7 @@ __global__ __launch_bounds__(WAVE) void k_call_sorted(
     }
 
     // ---- anything this kernel does not handle exactly goes to the table kernel
-    if (BAL(redo_m != 0)) {
+    if (BAL(redo_m != 0) || (L.flags & SMC_LF_SAMPLED)) {              // (host-sampled loci: table kernel)
         if (lane == 0) redo_flag[li] = 1;
         return;
     }

@@ -24,7 +24,7 @@ the on-chip tables (reads, barcodes, fragments) and the allele-table facts the k
 from __future__ import annotations
 
 import dataclasses
-from typing import List
+from typing import List, Optional
 
 import numpy as np
 
@@ -37,6 +37,8 @@ LOCUS_DTYPE = np.dtype([("read_off4", "<u4"), ("umi_off", "<u4"), ("n_reads", "<
 assert LOCUS_DTYPE.itemsize == 32
 
 FL_R2, FL_REV, FL_MMOK = 1, 2, 4
+LF_SAMPLED = 1                  # smc_locus.flags: host-applied down-sampling (include/smcounter_hip.h)
+USTART_DROPPED = 0x80000000
 KIND_SHIFT = 3
 KIND_BASE, KIND_INDEL_GAP, KIND_INS, KIND_DELSTART = 0, 1, 2, 3
 READ_ALIGN = 4
@@ -61,6 +63,7 @@ class DeviceBatch:
     pos: np.ndarray
     ref: List[str]
     alleles: List[List[str]]
+    umi_names: Optional[List[List[str]]] = None
 
     @property
     def n_loci(self) -> int:
@@ -212,6 +215,29 @@ def extract_features(pb: PileupBatch, params: VcParams) -> DeviceBatch:
                 mask |= 1 << a
         loci["snp_mask"][l] = mask
 
+    # --- the reference's down-sampling (smCounter.py:485-498), when the barcode texts are known: bcDict's keys
+    # are the barcodes with an included read, inserted in order of that read; more keys than ds -> py2
+    # random.sample seeded with the position string.  Dropped keys are marked in umi_start (bit 31).
+    if pb.umi_names is not None and n and params.ds > 0:      # (ds <= 0: usedMT = 0, Zero_Coverage anyway)
+        from .py2compat import py2_downsample_barcodes
+        inc = ((pb.bq.astype(np.int64) >= params.minBQ) | (kind == KIND_INDEL_GAP)) \
+            & (pb.mq.astype(np.int64) >= params.minMQ) & mm_ok
+        for l in np.nonzero(n_umi > params.ds)[0]:
+            s = pb.locus_slice(int(l))
+            ui = pb.umi[s][inc[s]]
+            _, first = np.unique(ui, return_index=True)
+            order = ui[np.sort(first)]                               # barcodes by first included read
+            if len(order) <= params.ds:
+                continue
+            names = pb.umi_names[int(l)]
+            kept = set(py2_downsample_barcodes(str(int(pb.pos[l])), [names[int(u)] for u in order], params.ds))
+            o = int(umi_off[l])
+            for u in order:
+                if names[int(u)] not in kept:
+                    umi_start[o + int(u)] |= USTART_DROPPED
+            loci["flags"][l] |= LF_SAMPLED
+
     return DeviceBatch(loci=loci, meta=plane(meta), umi=plane(pb.umi), frag=plane(slot),
                        dist=plane(dist), umi_start=umi_start, chrom=list(pb.chrom), pos=pb.pos.copy(),
-                       ref=list(pb.ref), alleles=[list(t) for t in pb.alleles])
+                       ref=list(pb.ref), alleles=[list(t) for t in pb.alleles],
+                       umi_names=None if pb.umi_names is None else [list(t) for t in pb.umi_names])

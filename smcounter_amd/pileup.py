@@ -20,7 +20,7 @@ appearance: 'INS|r|ra' / 'DEL|rd|r' strings (smCounter.py:374, :396) or any othe
 from __future__ import annotations
 
 import dataclasses
-from typing import List
+from typing import List, Optional
 
 import numpy as np
 
@@ -56,6 +56,9 @@ class PileupBatch:
     is_del: np.ndarray         # bool
     allele: np.ndarray         # uint8  id into alleles[locus]
     bq: np.ndarray             # uint8  base quality at qpos
+    # optional, per locus: the barcode strings by dense id (needed only to reproduce the reference's
+    # down-sampling, which depends on the py2 hash of the barcode text; smCounter.py:496-498)
+    umi_names: Optional[List[List[str]]] = None
 
     @property
     def n_loci(self) -> int:
@@ -79,10 +82,12 @@ class PileupBatch:
         else:
             take = np.zeros(0, np.int64)
         per_read = {f.name: getattr(self, f.name)[take] for f in dataclasses.fields(self)
-                    if f.name not in ("chrom", "pos", "ref", "alleles", "read_off")}
+                    if f.name not in ("chrom", "pos", "ref", "alleles", "read_off", "umi_names")}
         return PileupBatch(chrom=[self.chrom[i] for i in idx], pos=self.pos[idx].copy(),
                            ref=[self.ref[i] for i in idx],
-                           alleles=[list(self.alleles[i]) for i in idx], read_off=off, **per_read)
+                           alleles=[list(self.alleles[i]) for i in idx], read_off=off,
+                           umi_names=None if self.umi_names is None else [list(self.umi_names[i]) for i in idx],
+                           **per_read)
 
 
 def concat(batches: List[PileupBatch]) -> PileupBatch:
@@ -96,11 +101,14 @@ def concat(batches: List[PileupBatch]) -> PileupBatch:
     off[1:] = np.cumsum(lens)
     per_read = {}
     for f in dataclasses.fields(PileupBatch):
-        if f.name in ("chrom", "pos", "ref", "alleles", "read_off"):
+        if f.name in ("chrom", "pos", "ref", "alleles", "read_off", "umi_names"):
             continue
         per_read[f.name] = np.concatenate([getattr(b, f.name) for b in batches])
+    names = None
+    if batches and all(b.umi_names is not None for b in batches):
+        names = [n for b in batches for n in b.umi_names]
     return PileupBatch(chrom=chrom, pos=np.concatenate([b.pos for b in batches]), ref=ref,
-                       alleles=alleles, read_off=off, **per_read)
+                       alleles=alleles, read_off=off, umi_names=names, **per_read)
 
 
 def allele_kind(s: str) -> str:
@@ -122,6 +130,8 @@ def save_npz(path: str, pb: PileupBatch, **extra):
     """Compact on-disk form of a batch (used for the golden fixtures under tests/golden/)."""
     import json
     meta = dict(chrom=pb.chrom, ref=pb.ref, alleles=pb.alleles, extra=extra)
+    if pb.umi_names is not None:
+        meta["umi_names"] = pb.umi_names
     arrays = {k: getattr(pb, k) for k in _PER_READ}
     np.savez_compressed(path, pos=pb.pos, read_off=pb.read_off,
                         meta=np.frombuffer(json.dumps(meta).encode(), np.uint8), **arrays)
@@ -132,5 +142,5 @@ def load_npz(path: str):
     z = np.load(path)
     meta = json.loads(bytes(z["meta"]).decode())
     pb = PileupBatch(chrom=meta["chrom"], pos=z["pos"], ref=meta["ref"], alleles=meta["alleles"],
-                     read_off=z["read_off"], **{k: z[k] for k in _PER_READ})
+                     read_off=z["read_off"], umi_names=meta.get("umi_names"), **{k: z[k] for k in _PER_READ})
     return pb, meta["extra"]

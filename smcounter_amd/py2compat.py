@@ -116,3 +116,69 @@ def py2_dict_order(keys_in_insertion_order):
     for k in keys_in_insertion_order:
         d.insert(k)
     return d.keys()
+
+
+# ------------------------------------------------------------------------------------------------
+# random.seed(str) + random.sample(list, k) of CPython 2.7 (smCounter.py:496-498)
+# ------------------------------------------------------------------------------------------------
+class Py2Random(object):
+    """`random.seed(a)`, `random.random()`, `random.sample(list, k)` as CPython 2.7 computes them.
+
+    * Modules/_randommodule.c (2.7) `random_seed`: an int/long seeds with its absolute value; any other
+      object with `(unsigned long) hash(obj)` - for a `str` the unrandomised 64-bit string hash - split into
+      32-bit words, low word first, fed to MT19937 `init_by_array`.  CPython 3 seeds an `int` the same way,
+      so `random.Random(n)` of this interpreter reproduces the state; `random()` (genrand_res53) is unchanged.
+    * Lib/random.py (2.7) `sample`: `setsize = 21 (+ 4 ** ceil(log(3k, 4)) if k > 5)`; a list of
+      `n <= setsize` items is sampled by pool swaps `j = int(random() * (n - i))`, a longer one by rejection
+      `j = int(random() * n)` against a set of chosen indices (py3 draws with `_randbelow` instead).
+    """
+
+    def __init__(self, seed):
+        import random as _random
+        if isinstance(seed, int):
+            n = abs(seed)
+        elif isinstance(seed, str):
+            n = py2_str_hash(seed) & _M64
+        else:
+            raise TypeError("Py2Random: int or str seed")
+        self._r = _random.Random(n)
+
+    def random(self) -> float:
+        return self._r.random()
+
+    def sample(self, population, k: int):
+        import math
+        population = list(population)
+        n = len(population)
+        if not 0 <= k <= n:
+            raise ValueError("sample larger than population")
+        result = [None] * k
+        setsize = 21
+        if k > 5:
+            setsize += 4 ** math.ceil(math.log(k * 3, 4))
+        if n <= setsize:
+            pool = list(population)
+            for i in range(k):
+                j = int(self.random() * (n - i))
+                result[i] = pool[j]
+                pool[j] = pool[n - i - 1]
+        else:
+            selected = set()
+            for i in range(k):
+                j = int(self.random() * n)
+                while j in selected:
+                    j = int(self.random() * n)
+                selected.add(j)
+                result[i] = population[j]
+        return result
+
+
+def py2_downsample_barcodes(pos: str, barcodes_in_insertion_order, ds: int):
+    """`random.seed(pos); bcKeys = random.sample(bcDict.keys(), ds)` (smCounter.py:496-498): `pos` is the
+    locus position AS A STRING (vc() receives it as text, :274/:680), the population is the py2 dict key order
+    of the barcodes, inserted in order of their first included read (:467-468).  -> kept barcodes, in the
+    order the reference would iterate them."""
+    keys = py2_dict_order(barcodes_in_insertion_order)
+    if len(keys) <= ds:
+        return keys
+    return Py2Random(str(pos)).sample(keys, ds)

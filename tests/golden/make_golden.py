@@ -29,7 +29,33 @@ def emit(name, pb, params, chroms):
     pileup.save_npz(os.path.join(HERE, name + ".npz"), pb, params=dataclasses.asdict(params),
                     chroms=chroms, expected=res)
     n_amb = sum(r["tie_ambiguous"] for r in res)
-    print("%-14s %4d loci %7d reads  %d tie-ambiguous" % (name, pb.n_loci, pb.n_reads, n_amb))
+    print("%-14s %4d loci %7d reads  %d tie-ambiguous  %d down-sampled" % (name, pb.n_loci, pb.n_reads, n_amb,
+                                                                          sum(r.get("sampled", False) for r in res)))
+
+
+def with_names(pb, seed):
+    """Attach barcode texts (random 12-mers, unique per locus): the reference's down-sampling depends on them."""
+    import numpy as np
+    rng = np.random.RandomState(seed)
+    names = []
+    for l in range(pb.n_loci):
+        s = pb.locus_slice(l)
+        nu = int(pb.umi[s].max()) + 1 if s.stop > s.start else 0
+        seen = set()
+        while len(seen) < nu:
+            seen.add("".join(rng.choice(list("ACGT"), 12)))
+        names.append(sorted(seen, key=lambda t: rng.rand()))
+    return dataclasses.replace(pb, umi_names=names)
+
+
+def main_downsampled():
+    """Loci with more barcodes than the cap: `random.seed(pos); random.sample(bcDict.keys(), ds)` (smCounter.py:
+    496-498) runs inside the reference, through the CPython-2.7 emulation of seed(str) / sample / dict order
+    that oracle/ref_harness.py binds (py2compat.Py2Random) - unpinned against a real py2 (none available)."""
+    for name, seed, n, params in (("stress_ds1", 7, 60, VcParams(mtDepth=3, rpb=8.6, hpLen=8, mtDrop=0)),
+                                  ("stress_ds2", 8, 40, VcParams(mtDepth=500, rpb=2.0, hpLen=8, maxMT=5))):
+        pb, chroms = synth.generate_stress(n, seed)
+        emit(name, with_names(pb, seed), params, chroms)
 
 
 def main():
@@ -53,4 +79,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["downsampled"]:
+        main_downsampled()
+    else:
+        main()
+        main_downsampled()

@@ -240,14 +240,15 @@ def _assert_device_batches_equal(a, b):
     assert a.chrom == b.chrom and a.ref == b.ref and a.alleles == b.alleles
 
 
+@pytest.mark.parametrize("mt_depth", [1000, 4])        # 4 -> ds = 8 < 25 barcodes: the py2 down-sampling path
 @pytest.mark.parametrize("nthreads", [1, 3])
 @pytest.mark.parametrize("max_reads", [5000, 2_000_000])
-def test_native_fused_planes_match_extract_features(tmp_path, max_reads, nthreads):
+def test_native_fused_planes_match_extract_features(tmp_path, max_reads, nthreads, mt_depth):
     """smc_bam_planes (decode + features + barcode-major order in one native pass) builds the same
     DeviceBatch, chunk for chunk, as extract_features over the Python decoder's batches."""
     bam, fa_path, loci = _random_bam(tmp_path, 23, True)
     fa = fasta.FastaFile(fa_path)
-    P = VcParams(mismatchThr=4.0)
+    P = VcParams(mismatchThr=4.0, mtDepth=mt_depth)
     want = [(f, features.extract_features(pb, P))
             for f, pb in bamio.iter_pileup_batches(bamio.BamFile(bam), fa, loci, max_reads=max_reads)]
     got = list(bamio.iter_device_batches_native(bam, fa, loci, P, max_reads=max_reads, nthreads=nthreads))
@@ -256,6 +257,11 @@ def test_native_fused_planes_match_extract_features(tmp_path, max_reads, nthread
         _assert_device_batches_equal(a, b)
     flags = np.concatenate([b.meta for _, b in got]) >> 16 & 0xff
     assert len(set((flags >> 3).tolist())) == 4 and (flags & 4).any() and not (flags & 4).all()
+    sampled = np.concatenate([b.loci["flags"] for _, b in got]) & features.LF_SAMPLED
+    assert sampled.any() == (mt_depth == 4)
+    if mt_depth == 4:
+        us = np.concatenate([b.umi_start for _, b in got])
+        assert (us & features.USTART_DROPPED).any()
 
 
 def test_native_fused_planes_fixture_and_errors(tmp_path):

@@ -180,3 +180,24 @@ def test_sorted_stream_kernel_variant(monkeypatch):
         assert abi.compare_rows(got, want, PI_TOL, P_TOL, fragile) == []
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+def test_host_sampling_marks_are_checked(engine0):
+    """SMC_LF_SAMPLED loci (reference down-sampling applied by the host): the kernel keeps exactly the marked
+    subset (golden rows, above) and flags marks that do not keep min(#keys, ds) barcodes."""
+    import dataclasses
+    path = [p for p in golden_files() if "stress_ds1" in p][0]
+    pb, db, P, refp, expected = load_golden(path)
+    sampled = np.nonzero(db.loci["flags"] & 1)[0]
+    assert len(sampled) > 10
+    got = engine0.call_batch_host(db, P)
+    assert (got["status"][sampled] & abi.ST_DOWNSAMPLED).all() and (got["used_mt"][sampled] == P.ds).all()
+    bad = dataclasses.replace(db, umi_start=db.umi_start.copy())
+    l = int(sampled[0])
+    o = int(db.loci["umi_off"][l])
+    k = int(np.nonzero(bad.umi_start[o:o + int(db.loci["n_umi"][l])] >> 31)[0][0])
+    bad.umi_start[o + k] &= 0x7fffffff                   # one key too many
+    got = engine0.call_batch_host(bad, P)
+    assert got["status"][l] & abi.ST_BAD_INPUT
+    assert not (np.delete(got["status"], l) & abi.ST_BAD_INPUT).any()

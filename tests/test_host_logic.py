@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import dataclasses
+
 import numpy as np
 import pytest
 
@@ -175,3 +177,67 @@ def test_oracle_multithread_wrapper_matches_single_thread():
     a = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE)
     b = oracle_lib.call_batch_mt(db, abi.c_params(P), abi.ROW_DTYPE, 5)
     assert a.tobytes() == b.tobytes()
+
+
+def test_py2_random_and_downsampling_emulation():
+    """CPython-2.7 seed(str) / sample / dict-order emulation.  Pins available without a py2:
+    the 64-bit string hash of 'a' (12416037344), the MT19937 stream of an int seed (identical in py2 and py3),
+    the pool-vs-set switch of sample(), and self-consistency of the kept set."""
+    from smcounter_amd import py2compat as p
+    assert p.py2_str_hash("a") == 12416037344 and p.py2_str_hash("") == 0
+    assert p.Py2Random(1).random() == 0.13436424411240122
+    # a str seeds with its unsigned 64-bit hash, low word first == seeding with that integer
+    h = p.py2_str_hash("115256529") & ((1 << 64) - 1)
+    assert p.Py2Random("115256529").random() == p.Py2Random(h).random()
+    # pool branch (n <= 21): draws int(random() * (n - i)) with swaps
+    r1, r2 = p.Py2Random(5), p.Py2Random(5)
+    pop = list(range(20))
+    got = r1.sample(pop, 3)
+    pool, exp = list(pop), []
+    for i in range(3):
+        j = int(r2.random() * (20 - i)); exp.append(pool[j]); pool[j] = pool[20 - i - 1]
+    assert got == exp
+    # set branch (n > setsize): rejection on indices
+    r1, r2 = p.Py2Random(6), p.Py2Random(6)
+    pop = list(range(100))
+    got = r1.sample(pop, 4)
+    sel, exp = set(), []
+    for i in range(4):
+        j = int(r2.random() * 100)
+        while j in sel:
+            j = int(r2.random() * 100)
+        sel.add(j); exp.append(pop[j])
+    assert got == exp
+    names = ["ACGTACGTAC%02d" % i for i in range(40)]
+    kept = p.py2_downsample_barcodes("1000", names, 10)
+    assert len(kept) == len(set(kept)) == 10 and set(kept) <= set(names)
+    assert p.py2_downsample_barcodes("1000", names, 10) == kept            # deterministic
+    assert p.py2_downsample_barcodes("1001", names, 10) != kept            # seeded by the position text
+    assert p.py2_downsample_barcodes("1000", names[:8], 10) == p.py2_dict_order(names[:8])
+
+
+def test_downsampled_golden_fixtures_exercise_the_sample():
+    import conftest
+    from smcounter_amd import abi
+    import oracle_lib
+    n = 0
+    for path in conftest.golden_files():
+        if "stress_ds" not in path:
+            continue
+        pb, db, P, refp, expected = conftest.load_golden(path)
+        sampled = np.array([e["sampled"] for e in expected])
+        assert sampled.sum() >= 30
+        assert ((db.loci["flags"] & 1) != 0).tolist() == sampled.tolist()
+        R = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE)
+        assert ((R["status"] & abi.ST_DOWNSAMPLED) != 0).tolist() == sampled.tolist()
+        assert (R["used_mt"][sampled] == P.ds).all()
+        # marks that do not keep exactly ds keys are a contract violation
+        bad = dataclasses.replace(db, umi_start=db.umi_start.copy())
+        l = int(np.nonzero(sampled)[0][0])
+        o = int(db.loci["umi_off"][l])
+        k = int(np.nonzero(bad.umi_start[o:o + int(db.loci["n_umi"][l])] >> 31)[0][0])
+        bad.umi_start[o + k] &= 0x7fffffff
+        R2 = oracle_lib.call_batch(bad, abi.c_params(P), abi.ROW_DTYPE)
+        assert R2["status"][l] & abi.ST_BAD_INPUT
+        n += 1
+    assert n == 2
