@@ -298,6 +298,51 @@ def write_bai(bam_path: str) -> str:
     return bam_path + ".bai"
 
 
+def iter_raw_records(path: str):
+    """(header bytes up to the first record, iterator of (tid, qname, raw record incl. its block_size))."""
+    bam = BamFile(path)
+    bg = bam._bg
+    bg.seek(0)
+    n_head = None
+    # header length in uncompressed bytes: re-read it sequentially
+    hdr = bytearray()
+    magic = bg.read(4)
+    l_text = bg.read(4)
+    text = bg.read(struct.unpack("<i", l_text)[0])
+    n_ref_b = bg.read(4)
+    hdr += magic + l_text + text + n_ref_b
+    for _ in range(struct.unpack("<i", n_ref_b)[0]):
+        ln = bg.read(4)
+        rest = bg.read(struct.unpack("<i", ln)[0] + 4)
+        hdr += ln + rest
+
+    def records():
+        while True:
+            h = bg.read(4)
+            if len(h) < 4:
+                break
+            body = bg.read(struct.unpack("<i", h)[0])
+            tid = struct.unpack_from("<i", body, 0)[0]
+            l_name = body[8]
+            yield tid, body[32:32 + l_name - 1].decode(), h + body
+        bam.close()
+    return bytes(hdr), records()
+
+
+def write_raw(path: str, header: bytes, raw_records: Iterable[bytes], block: int = 60000) -> None:
+    """BGZF-compress a header and raw BAM records (as `iter_raw_records` yields them) into a BAM file."""
+    with open(path, "wb") as fh:
+        buf = bytearray(header)
+        for r in raw_records:
+            buf += r
+            while len(buf) >= block:
+                fh.write(_bgzf_block(bytes(buf[:block])))
+                del buf[:block]
+        if buf:
+            fh.write(_bgzf_block(bytes(buf)))
+        fh.write(_bgzf_block(b""))
+
+
 # ------------------------------------------------------------------------------------------------
 # pileup
 # ------------------------------------------------------------------------------------------------
