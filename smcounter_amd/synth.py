@@ -86,6 +86,11 @@ CONFIGS = {
     "C3": SynthConfig("C3", 200_000, 50, 60, 20170413),
     "C4": SynthConfig("C4", 1_000_000, 50, 60, 20170414),
     "C5": SynthConfig("C5", 100_000, 133, 60, 20170415, alt_locus_frac=0.01, alt_af=0.005),
+    # the shape of the reference's own example run (example.run-log: 2000 loci, ~ 58 k reads each, 3612 barcodes
+    # x 8.6 reads, README.md / run.example.sh) and a mid-depth panel shape; not BASELINE configs, used by
+    # scripts/quick_perf.py to watch the deep-locus launch classes (512 / 1024 threads, global tables)
+    "X1": SynthConfig("X1", 2_000, 3600, 9, 20170420),
+    "X2": SynthConfig("X2", 20_000, 600, 10, 20170421),
 }
 
 
