@@ -13,13 +13,14 @@
 // fragment ids dense per barcode, so the on-chip tables are directly indexed (no hashing).
 //
 // On-chip tables per locus (dynamic LDS, or a global scratch slab for loci that do not fit):
-//   umi_base[nU+1]  fragments-per-barcode (atomicMax) then their exclusive prefix sum
-//   umi_flag[nU]    barcode has an included read (= is a key of bcDict)
-//   fmin/fmax[nF]   per fragment: smallest / largest packed key (read index | allele | quality)
-//                   of its included reads; read order matters to the reference (first mate
-//                   defines the base, :468-479) and min/max of the index recovers it without a
-//                   sort for fragments with <= 2 included reads; the rare longer ones are
-//                   replayed sequentially.
+//   umi_base[nU+1]  first fragment slot of each barcode (slot of its first read, from umi_start)
+//   frag word[nF]   one 32-bit word per fragment: (allele, quality) of its first and of its second
+//                   included read, in pileup order - which is memory order, a fragment's reads being
+//                   adjacent in the barcode-major batch: a read is "second" when the read just before it
+//                   has the same slot and is included (smCounter.py:468-479 depends on that order).
+//                   Written with one LDS atomicOr per included read; slots with >= 3 reads are flagged
+//                   and replayed sequentially.  The merge then overwrites it with the fragment's state.
+//   worklist[nU], umi_flag[nU], chunk masks (2 x u64 per 64 slots): see the U phase.
 // This is integer/branchy, HBM-streaming work: no MFMA.
 #include <hip/hip_runtime.h>
 
@@ -195,6 +196,11 @@ __device__ __forceinline__ uint32_t make_key(int idx, int allele, int bq) {
 // a sequencer) take a slow path through the global table.
 #define ST_PRESENT 0x80000000u
 #define ST_PAIRED 0x40000000u
+// raw fragment word (P1): first read in bits 0-13 (allele << 8 | quality), second in 14-27
+#define FW_HAS1 0x10000000u
+#define FW_HAS2 0x20000000u
+#define FW_OVERFLOW 0x40000000u   // three or more reads share the slot: exact replay
+#define ST_MARK 0x08000000u       // (after R) slot waits for the replay
 #define ST_HAD 0x20000000u     // slot had included reads (its barcode is a key of bcDict) but the fragment was deleted
 #define PIDX_UNPAIRED 127u
 __device__ __forceinline__ uint32_t make_state(int allele, int bq, bool paired) {
@@ -364,8 +370,12 @@ __device__ __forceinline__ void finish_row(smc_row* R, const smc_locus& L, int l
 #ifndef SMC_G_FRAGS
 #define SMC_G_FRAGS 24
 #endif
+// 6 waves per SIMD (<= 80 VGPRs; LDS allows 14 workgroups of 2 waves per CU on the C3 shape): measured best of 4..8
 #ifndef SMC_WAVES_PER_EU
-#define SMC_WAVES_PER_EU 4
+#define SMC_WAVES_PER_EU 6
+#endif
+#ifndef SMC_WALK_UNROLL
+#define SMC_WALK_UNROLL 2
 #endif
 template <int BLOCK, bool GLOBAL_TABLES>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES_PER_EU, 8))) void k_call_loci(
@@ -397,17 +407,26 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
     static_assert(sizeof(smc_row) <= LUT_N * sizeof(double), "row stage must fit in the LUT");
     unsigned char* tab = GLOBAL_TABLES ? (scratch + scratch_off[blockIdx.x]) : (smem + lds_hdr_bytes(a_cap));
     uint32_t* umi_base = (uint32_t*)tab;                              // [nU+1] first slot of each barcode
-    uint32_t* fmin = umi_base + (nU + 1);                             // [nF]
-    uint32_t* fmax = fmin + nF;                                       // [nF]
-    unsigned char* umi_flag = (unsigned char*)(fmax + nF);            // [nU]
+    uint32_t* fmin = umi_base + (nU + 1);                             // [nF] fragment word: raw (P1) then state (R)
+    uint32_t* worklist = fmin + nF;                                   // [nU] barcodes queued for the general calProb path
+    unsigned char* umi_flag = (unsigned char*)(worklist + nU);        // [nU]
     // per 64 fragment slots, after the merge: which slots hold a fragment, which of those show the reference allele
-    unsigned long long* cmask = (unsigned long long*)(tab + ((4u * (uint32_t)(nU + 1) + 8u * (uint32_t)nF + (uint32_t)nU + 7u) & ~7u));
+    unsigned long long* cmask = (unsigned long long*)(tab + ((4u * (uint32_t)(nU + 1) + 4u * (uint32_t)nF + 5u * (uint32_t)nU + 7u) & ~7u));
 
     STAMP_INIT();
     // first step's reads are requested before the LDS image is initialised (HBM latency overlaps it)
     const int n4 = (n + 3) >> 2;
     uint4 m4, f4, d4;
-    if (tid < n4) { m4 = meta4[tid]; f4 = frag4[tid]; d4 = dist4[tid]; }
+    // + the two reads before the lane's quad (slot of both, meta of the last): a read's rank inside its fragment
+    // comes from its predecessors, which sit right before it in barcode-major order
+    uint2 pf2 = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+    uint32_t pm1 = 0;
+    const uint2* frag2 = (const uint2*)frag4;
+    if (tid < n4) {
+        m4 = meta4[tid]; f4 = frag4[tid]; d4 = dist4[tid];
+        // (only the first lane of a wavefront fetches them; the others take them from their neighbour lane)
+        if (lane == 0 && tid > 0) { pf2 = frag2[2 * tid - 1]; pm1 = ((const uint32_t*)meta4)[4 * tid - 1]; }
+    }
     // quality -> error-probability table: requested now, parked in registers, stored to LDS after the
     // scan (its first reader is the calProb phase), so no phase waits on this load
     double lut_reg[(LUT_N + BLOCK - 1) / BLOCK];
@@ -422,7 +441,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         uint32_t* z = (uint32_t*)smem;
         const int nz = (int)((sizeof(Hdr) + a_cap * 64) / 4);
         for (int i = tid; i < nz; i += BLOCK) z[i] = 0;
-        for (int i = tid; i < nF; i += BLOCK) { fmin[i] = 0xFFFFFFFFu; fmax[i] = 0u; }
+        for (int i = tid; i < nF; i += BLOCK) fmin[i] = 0u;
         // first read of every barcode (+ closing entry); S2 turns it into the first fragment slot
         const uint32_t* ustart = g_umi_start + L.umi_off;
         for (int i = tid; i <= nU; i += BLOCK) umi_base[i] = ustart[i] & ~SMC_USTART_DROPPED;
@@ -450,17 +469,36 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
 #pragma unroll
         for (int k = 0; k < 9; ++k) accv[k] = 0;
         uint32_t n_inc_s = 0;
-        lmask err_m = 0;
+        lmask err_m = 0, ovf_any = 0;
         const uint32_t refa = L.ref_allele;
         for (int qb = 0; qb < n4; qb += BLOCK) {
             const int q = qb + tid;
             const uint4 cm = m4, cf = f4, cd = d4;
+            const uint2 cpf = pf2;
+            const uint32_t cpm = pm1;
             {   // prefetch the next step while this one is processed
                 const int qn = q + BLOCK;
-                if (qn < n4) { m4 = meta4[qn]; f4 = frag4[qn]; d4 = dist4[qn]; }
+                if (qn < n4) {
+                    m4 = meta4[qn]; f4 = frag4[qn]; d4 = dist4[qn];
+                    if (lane == 0) { pf2 = frag2[2 * qn - 1]; pm1 = ((const uint32_t*)meta4)[4 * qn - 1]; }
+                }
             }
             const uint32_t ms[4] = {cm.x, cm.y, cm.z, cm.w};
             const uint32_t fs[4] = {cf.x, cf.y, cf.z, cf.w}, ds[4] = {cd.x, cd.y, cd.z, cd.w};
+            // slots of the two reads before the quad: the neighbour lane's last two (wavefront shift right by one
+            // lane, DPP), lane 0 keeps what it loaded; inclusion of the read just before the quad likewise
+            // (same test as below - the neighbour's fourth read, or lane 0's loaded word)
+            const uint32_t fprev1 = (uint32_t)__builtin_amdgcn_update_dpp((int)cpf.y, (int)fs[3], 0x138, 0xF, 0xF, false);
+            const uint32_t fprev2 = (uint32_t)__builtin_amdgcn_update_dpp((int)cpf.x, (int)fs[2], 0x138, 0xF, 0xF, false);
+            lmask m_inc_prev;
+            {
+                auto inc_of = [&](uint32_t w) {
+                    return (BAL((int)((w >> 8) & 0xffu) >= P.min_bq) | BAL(((w >> 19) & 3u) == SMC_KIND_GAP)) &
+                           BAL((int)(w >> 24) >= P.min_mq) & BAL((w & 0x40000u) != 0u);
+                };
+                const lmask m_ok3 = BAL(4 * q + 3 < n) & BAL(fs[3] < (uint32_t)nF) & BAL((ms[3] & 0xffu) < (uint32_t)nA);
+                m_inc_prev = ((inc_of(ms[3]) & m_ok3) << 1) | (inc_of(cpm) & BAL(q > 0) & 1ull);
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int i = 4 * q + k;
@@ -523,13 +561,26 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                     }
                 }
                 {
-                    if (LANES(m_inc)) {
+                    // The fragment word: (allele, quality) of its first and of its second read, in pileup order
+                    // (= memory order: a fragment's reads are adjacent).  A read is second when the read before it
+                    // has the same slot and is included; a slot with three or more reads is flagged for the
+                    // exact replay below.
+                    const uint32_t fp1 = k == 0 ? fprev1 : fs[k > 0 ? k - 1 : 0];
+                    const uint32_t fp2 = k == 0 ? fprev2 : (k == 1 ? fprev1 : fs[k > 1 ? k - 2 : 0]);
+                    const lmask m_same1 = BAL(f == fp1);
+                    const lmask m_second = m_same1 & m_inc_prev;
+                    const lmask m_ovf = m_ok & m_same1 & BAL(f == fp2);
+                    ovf_any |= m_ovf;
+                    if (LANES(m_inc | m_ovf)) {
                         uint32_t bq_eff = LANES(m_gap) ? (uint32_t)P.min_bq : ((mw >> 8) & 0xffu);         // :418
                         bq_eff = bq_eff < PIDX_UNPAIRED ? bq_eff : PIDX_UNPAIRED - 1u;   // contract: quality <= 126
-                        const uint32_t key = ((uint32_t)i << 14) | (a << 8) | bq_eff;
-                        atomicMin(&fmin[f], key);
-                        atomicMax(&fmax[f], key);
+                        uint32_t w = (a << 8) | bq_eff;
+                        w = LANES(m_second) ? (w << 14) | FW_HAS2 : w | FW_HAS1;
+                        w = LANES(m_inc) ? w : 0u;
+                        w |= LANES(m_ovf) ? FW_OVERFLOW : 0u;
+                        atomicOr(&fmin[f], w);
                     }
+                    m_inc_prev = m_inc;
                 }
             }
         }
@@ -540,6 +591,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         }
         if (lane == 0 && n_inc_s) atomicAdd(&H->misc[M_NINC], n_inc_s);
         if (err_m && lane == 0) H->misc[M_ERR] = 1;
+        if (ovf_any && lane == 0) H->misc[M_NEEDFIX] = 1;
 #pragma unroll
         for (int t = 0; t < (LUT_N + BLOCK - 1) / BLOCK; ++t) {
             const int i = tid + t * BLOCK;
@@ -603,27 +655,27 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         return;
     }
 
-    // ---- R: mate merge (smCounter.py:468-479), assuming every fragment has <= 2 included reads;
-    // the count of reads so explained is checked against the number of included reads below.
-    auto resolve = [&](bool honour_marks) {
-        uint32_t c = 0, conc_ref = 0, disc_ref = 0;                      // wave-uniform counts
+    // ---- R: mate merge (smCounter.py:468-479) from the fragment words; slots flagged FW_OVERFLOW wait for the
+    // exact replay below.
+    {
+        uint32_t conc_ref = 0, disc_ref = 0;                             // wave-uniform counts
         const uint32_t refa = L.ref_allele;
         // one chunk of 64 slots per wavefront: classify, write the state word, leave the chunk masks
-        auto chunk = [&](int s, lmask m_in, uint32_t a, uint32_t b) {
-            const lmask m_marked = honour_marks ? (m_in & BAL(b == 0xFFFFFFFFu)) : 0ull;
-            const lmask m_has = m_in & ~m_marked & BAL(a != 0xFFFFFFFFu);
-            const lmask m_single = m_has & BAL(a == b), m_pair = m_has & ~m_single;
-            const uint32_t a1 = (a >> 8) & 63u, a2 = (b >> 8) & 63u, q1 = a & 255u, q2 = b & 255u;
+        auto chunk = [&](int s, lmask m_in, uint32_t w) {
+            const lmask m_marked = m_in & BAL((w & FW_OVERFLOW) != 0u);
+            const lmask m_has = m_in & ~m_marked & BAL((w & FW_HAS1) != 0u);
+            const lmask m_pair = m_has & BAL((w & FW_HAS2) != 0u), m_single = m_has & ~m_pair;
+            const uint32_t a1 = (w >> 8) & 63u, a2 = (w >> 22) & 63u, q1 = w & 255u, q2 = (w >> 14) & 255u;
             const lmask m_same = BAL(a1 == a2);
             const lmask m_merge = m_pair & (m_same | BAL(a2 == (uint32_t)N_ID));
             const lmask m_conc = m_pair & m_same, m_disc = m_pair & ~m_merge;   // :475-476 / :478-479
-            c += (uint32_t)__popcll(m_single) + 2u * (uint32_t)__popcll(m_pair);
             // state: first read's allele; prob = max(prob_new, prob_old) <=> min quality (:473)
             uint32_t st = 0u;
             if (LANES(m_has)) st = ST_HAD;                                // discordant pair: deleted (:477-479)
-            if (LANES(m_single)) st = ST_PRESENT | (a & 0x3F00u) | PIDX_UNPAIRED;
-            if (LANES(m_merge)) st = ST_PRESENT | ST_PAIRED | (a & 0x3F00u) | (q1 < q2 ? q1 : q2);
-            if (LANES(m_in & ~m_marked)) fmin[s] = st;
+            if (LANES(m_single)) st = ST_PRESENT | (w & 0x3F00u) | PIDX_UNPAIRED;
+            if (LANES(m_merge)) st = ST_PRESENT | ST_PAIRED | (w & 0x3F00u) | (q1 < q2 ? q1 : q2);
+            if (LANES(m_marked)) st = ST_MARK;
+            if (LANES(m_in)) fmin[s] = st;
             const lmask m_a1ref = BAL(a1 == refa);
             if (lane == 0 && s < nF) {                                   // chunk masks for the calProb phase
                 const lmask m_live = m_single | m_merge;
@@ -639,62 +691,34 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                 if (LANES(m_disc & ~d_ref)) atomicAdd(&tal[a2 * SMC_NT + SMC_T_DISCORD], 1u);
             }
         };
-        // two chunks per step, their four LDS reads issued together
+        // two chunks per step, their LDS reads issued together
         for (int sb = 0; sb < nF; sb += 2 * BLOCK) {
             const int s0 = sb + tid, s1 = s0 + BLOCK;
             const lmask in0 = BAL(s0 < nF), in1 = BAL(s1 < nF);
-            uint32_t a0 = 0xFFFFFFFFu, b0 = 0u, a1 = 0xFFFFFFFFu, b1 = 0u;
-            if (LANES(in0)) { a0 = fmin[s0]; b0 = fmax[s0]; }
-            if (LANES(in1)) { a1 = fmin[s1]; b1 = fmax[s1]; }
-            chunk(s0, in0, a0, b0);
-            if (in1) chunk(s1, in1, a1, b1);
+            uint32_t w0 = 0u, w1 = 0u;
+            if (LANES(in0)) w0 = fmin[s0];
+            if (LANES(in1)) w1 = fmin[s1];
+            chunk(s0, in0, w0);
+            if (in1) chunk(s1, in1, w1);
         }
         if (lane == 0 && refa < (uint32_t)nA) {
             if (conc_ref) atomicAdd(&tal[refa * SMC_NT + SMC_T_CONCORD], conc_ref);
             if (disc_ref) atomicAdd(&tal[refa * SMC_NT + SMC_T_DISCORD], disc_ref);
         }
-        return c;
-    };
-    {
-        const uint32_t c = resolve(false);                               // already a per-wave total
-        if (lane == 0 && c) atomicAdd(&H->misc[M_RESOLVED], c);
     }
     __syncthreads();
     STAMP(4);
     if (SMC_ABLATE == 3) return;
-    if (H->misc[M_RESOLVED] != H->misc[M_NINC]) {
-        // Some read name has >= 3 included alignments on this locus (rare): redo the fragment table,
-        // mark those fragments, resolve the others as above and replay the marked ones in read order.
+    if (H->misc[M_NEEDFIX]) {
+        // Some read name has three or more alignments on this locus (rare): replay each flagged fragment
+        // sequentially in read order, one wavefront per fragment, then rebuild the chunk masks.
         const uint32_t* meta = g_meta + 4ll * L.read_off4;
         const uint32_t* frag = g_frag + 4ll * L.read_off4;
-        for (int i = tid; i < nF; i += BLOCK) { fmin[i] = 0xFFFFFFFFu; fmax[i] = 0u; }
-        for (int a = tid; a < a_cap; a += BLOCK) tal[a * SMC_NT + SMC_T_CONCORD] = tal[a * SMC_NT + SMC_T_DISCORD] = 0;
-        __syncthreads();
-        for (int i = tid; i < n; i += BLOCK) {
-            ReadRec r = decode_read(meta[i], 0, P);
-            if (r.inc) {
-                const uint32_t key = make_key(i, r.allele, r.bq_eff);
-                atomicMin(&fmin[frag[i]], key);
-                atomicMax(&fmax[frag[i]], key);
-            }
-        }
-        __syncthreads();
-        for (int i = tid; i < n; i += BLOCK) {
-            ReadRec r = decode_read(meta[i], 0, P);
-            if (r.inc) {
-                const uint32_t s = frag[i], key = make_key(i, r.allele, r.bq_eff);
-                const uint32_t lo = fmin[s], hi = fmax[s];
-                if (key != lo && key != hi) fmax[s] = 0xFFFFFFFFu;       // idempotent marker
-            }
-        }
-        __syncthreads();
-        (void)resolve(true);
-        __syncthreads();
         constexpr int NW = BLOCK / WAVE;
         for (int sb = 0; sb < nF; ++sb) {
-            if (fmax[sb] != 0xFFFFFFFFu) continue;            // uniform over the block (LDS value)
+            if (fmin[sb] != ST_MARK) continue;                // uniform over the block (LDS value)
             if ((sb % NW) != wid) continue;                   // one wave per marked fragment
-            bool present = false, paired = false;
+            bool present = false, paired = false, had = false;
             int sa = 0, sq = 0;
             for (int base = 0; base < n; base += WAVE) {
                 const int i = base + lane;
@@ -710,6 +734,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                     const int src = __ffsll((long long)hm) - 1;
                     hm &= hm - 1;
                     const int a = __shfl(r.allele, src), q = __shfl(r.bq_eff, src);
+                    had = true;
                     if (!present) { present = true; paired = false; sa = a; sq = q; }
                     else if (a == sa || a == N_ID) {
                         sq = q < sq ? q : sq; paired = true;
@@ -720,7 +745,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                     }
                 }
             }
-            if (lane == 0) fmin[sb] = present ? make_state(sa, paired ? sq : (int)PIDX_UNPAIRED, paired) : ST_HAD;
+            if (lane == 0)
+                fmin[sb] = present ? make_state(sa, paired ? sq : (int)PIDX_UNPAIRED, paired) : (had ? ST_HAD : 0u);
         }
         __syncthreads();
         for (int sb = 0; sb < nF; sb += BLOCK) {                          // chunk masks from the final states
@@ -765,18 +791,22 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
             unsigned long long mk = 0;
             rightP = 1.0; prod_ref = 1.0; prod_x = 1.0;
             {
-                // four slots per lane per step, independent partial products (the walk is a chain of
-                // dependent LDS reads and FP64 multiplies: instruction-level parallelism hides it)
-                double rp[4] = {1.0, 1.0, 1.0, 1.0}, pr[4] = {1.0, 1.0, 1.0, 1.0}, px[4] = {1.0, 1.0, 1.0, 1.0};
-                for (int s0 = b0 + jc; s0 < b1; s0 += 4 * Gc) {
-                    uint32_t st[4];
+                // WU slots per lane per step, independent partial products (the walk is a chain of dependent
+                // LDS reads and FP64 multiplies: instruction-level parallelism hides it; two keep the
+                // register count low enough for 6 waves per SIMD)
+                constexpr int WU = SMC_WALK_UNROLL;
+                double rp[WU], pr[WU], px[WU];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) { const int s = s0 + t * Gc; st[t] = s < b1 ? fmin[s] : 0u; }
-                    double pv[4];
+                for (int t = 0; t < WU; ++t) rp[t] = pr[t] = px[t] = 1.0;
+                for (int s0 = b0 + jc; s0 < b1; s0 += WU * Gc) {
+                    uint32_t st[WU];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) pv[t] = prob_of(st[t]);
+                    for (int t = 0; t < WU; ++t) { const int s = s0 + t * Gc; st[t] = s < b1 ? fmin[s] : 0u; }
+                    double pv[WU];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
+                    for (int t = 0; t < WU; ++t) pv[t] = prob_of(st[t]);
+#pragma unroll
+                    for (int t = 0; t < WU; ++t) {
                         const bool present = (st[t] & ST_PRESENT) != 0u;
                         const int a = KEY_ALLELE(st[t]);
                         const bool same = a == refa;
@@ -789,9 +819,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                         px[t] *= present ? (same ? pv[t] : q1) : 1.0;   // P(reads | the other allele), if there is just one
                     }
                 }
-                rightP = (rp[0] * rp[1]) * (rp[2] * rp[3]);
-                prod_ref = (pr[0] * pr[1]) * (pr[2] * pr[3]);
-                prod_x = (px[0] * px[1]) * (px[2] * px[3]);
+                rightP = rp[0]; prod_ref = pr[0]; prod_x = px[0];
+#pragma unroll
+                for (int t = 1; t < WU; ++t) { rightP *= rp[t]; prod_ref *= pr[t]; prod_x *= px[t]; }
             }
             nf = grp8_add(nf);
             cnt_ref = grp8_add(cnt_ref);
@@ -804,8 +834,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
 
         // ---- phase 0: one lane per barcode.  Fragment count and "every fragment shows the reference allele"
         // come from the chunk masks the merge left (no walk); such barcodes (nearly all) are scored from the
-        // per-count table, the others are queued (fmax[] is dead after the merge)
-        uint32_t* worklist = fmax;
+        // per-count table, the others are queued
         // fragment count / reference-only count / "is a key of bcDict" (:467-468: has an included read, even if
         // every fragment was deleted later) of barcode u
         auto barcode_counts = [&](int u, int& nf, int& cr, unsigned long long& live1, uint32_t& c1) -> bool {
@@ -902,6 +931,28 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         if (!two_pass) {
             nb1 = (uint32_t)wave_add((int)nb1);
             if (lane == 0 && nb1) atomicAdd(&H->misc[M_NBC], nb1);
+        }
+        // flush phase 0's lane accumulators (order-independent integer adds); phase 1 adds straight to LDS, so
+        // none of these registers stays live through its FP64 code
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const long long p = wave_add64(pi_acc[a]);
+            const int m = wave_add(mt_acc[a]), s = wave_add(st_acc[a]);
+            if (lane == 0) {
+                if (p) atomicAdd(&pifx[a], (unsigned long long)p);
+                if (m) atomicAdd(&mtc[a], (uint32_t)m);
+                if (s) atomicAdd(&strong[a], (uint32_t)s);
+            }
+        }
+        c3 = wave_add(c3); c5 = wave_add(c5);
+        c7 = wave_add(c7); c10 = wave_add(c10);
+        ufrag = wave_add(ufrag);
+        touch_lo = wave_or(touch_lo); touch_hi = wave_or(touch_hi);
+        if (lane == 0) {
+            atomicAdd(&H->misc[M_MT3], (uint32_t)c3); atomicAdd(&H->misc[M_MT5], (uint32_t)c5);
+            atomicAdd(&H->misc[M_MT7], (uint32_t)c7); atomicAdd(&H->misc[M_MT10], (uint32_t)c10);
+            atomicAdd(&H->misc[M_USEDFRAG], (uint32_t)ufrag);
+            atomicOr(&H->misc[M_TOUCH_LO], touch_lo); atomicOr(&H->misc[M_TOUCH_HI], touch_hi);
         }
         __syncthreads();
         STAMP(6);
@@ -1033,12 +1084,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                     const long long fx = to_fx(mypred, fxscale);
                     if (jc < n_exist) {
                         const int a = jc == 0 ? ida[0] : jc == 1 ? ida[1] : jc == 2 ? ida[2] : ida[3];
-                        if (a >= 4) atomicAdd(&pifx[a], (unsigned long long)fx);
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) pi_acc[b] += (b == a) ? fx : 0ll;
+                        atomicAdd(&pifx[a], (unsigned long long)fx);
                     } else if (npad) {
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) pi_acc[b] += ((padmask >> b) & 1ull) ? fx : 0ll;
+                        for (int b = 0; b < 4; ++b)
+                            if ((padmask >> b) & 1ull) atomicAdd(&pifx[b], (unsigned long long)fx);
                     }
                 }
                 if (jc == 0) {
@@ -1052,14 +1101,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                             if ((padmask >> a) & 1ull) { ++n_max; cons = a; }
                     }
                     const unsigned long long uq = mask | padmask;
-                    touch_lo |= (uint32_t)uq; touch_hi |= (uint32_t)(uq >> 32);
+                    atomicOr(&H->misc[M_TOUCH_LO], (uint32_t)uq); atomicOr(&H->misc[M_TOUCH_HI], (uint32_t)(uq >> 32));
                     if (n_max == 1) {                                                    // :515-519
                         const bool str = mx > P.smt;
-                        if (cons < 4) { mt_acc[cons]++; st_acc[cons] += str; }
-                        else { atomicAdd(&mtc[cons], 1u); if (str) atomicAdd(&strong[cons], 1u); }
+                        { atomicAdd(&mtc[cons], 1u); if (str) atomicAdd(&strong[cons], 1u); }
                     } else if (nf == 1) {                                                // :521-523
                         const int a = ida[0];
-                        if (a < 4) mt_acc[a]++; else atomicAdd(&mtc[a], 1u);
+                        atomicAdd(&mtc[a], 1u);
                     }
                 }
             } else {
@@ -1110,39 +1158,17 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                     else if (pred == mx) ++n_max;
                     if (jc == 0) {
                         const long long fx = to_fx(pred, fxscale);
-                        if (a < 4) pi_acc[a] += fx; else atomicAdd(&pifx[a], (unsigned long long)fx);
+                        atomicAdd(&pifx[a], (unsigned long long)fx);
                     }
                 }
                 if (jc == 0) {
-                    touch_lo |= (uint32_t)mask; touch_hi |= (uint32_t)(mask >> 32);
+                    atomicOr(&H->misc[M_TOUCH_LO], (uint32_t)mask); atomicOr(&H->misc[M_TOUCH_HI], (uint32_t)(mask >> 32));
                     if (n_max == 1) {
                         const bool str = mx > P.smt;
-                        if (cons < 4) { mt_acc[cons]++; st_acc[cons] += str; }
-                        else { atomicAdd(&mtc[cons], 1u); if (str) atomicAdd(&strong[cons], 1u); }
+                        { atomicAdd(&mtc[cons], 1u); if (str) atomicAdd(&strong[cons], 1u); }
                     }
                 }
             }
-        }
-        // flush lane accumulators (order-independent integer adds)
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const long long p = wave_add64(pi_acc[a]);
-            const int m = wave_add(mt_acc[a]), s = wave_add(st_acc[a]);
-            if (lane == 0) {
-                if (p) atomicAdd(&pifx[a], (unsigned long long)p);
-                if (m) atomicAdd(&mtc[a], (uint32_t)m);
-                if (s) atomicAdd(&strong[a], (uint32_t)s);
-            }
-        }
-        c3 = wave_add(c3); c5 = wave_add(c5);
-        c7 = wave_add(c7); c10 = wave_add(c10);
-        ufrag = wave_add(ufrag);
-        touch_lo = wave_or(touch_lo); touch_hi = wave_or(touch_hi);
-        if (lane == 0) {
-            atomicAdd(&H->misc[M_MT3], (uint32_t)c3); atomicAdd(&H->misc[M_MT5], (uint32_t)c5);
-            atomicAdd(&H->misc[M_MT7], (uint32_t)c7); atomicAdd(&H->misc[M_MT10], (uint32_t)c10);
-            atomicAdd(&H->misc[M_USEDFRAG], (uint32_t)ufrag);
-            atomicOr(&H->misc[M_TOUCH_LO], touch_lo); atomicOr(&H->misc[M_TOUCH_HI], touch_hi);
         }
         __syncthreads();
         STAMP(7);
@@ -1749,7 +1775,7 @@ static size_t host_hdr_bytes(int a_cap) {
     return sizeof(Hdr) + (size_t)a_cap * SMC_NT * 4 + (size_t)a_cap * 8 + (size_t)a_cap * 4 + (size_t)a_cap * 4 + 128 * 8;
 }
 static size_t table_bytes(const smc_locus& L) {
-    size_t b = 4 * ((size_t)L.n_umi + 1) + 8 * (size_t)L.n_frag + (size_t)L.n_umi;
+    size_t b = 4 * ((size_t)L.n_umi + 1) + 4 * (size_t)L.n_frag + 5 * (size_t)L.n_umi;
     b = (b + 7) & ~(size_t)7;
     b += 16 * (((size_t)L.n_frag + 63) / 64);             // chunk masks (live, live & reference allele)
     return (b + 15) & ~(size_t)15;
