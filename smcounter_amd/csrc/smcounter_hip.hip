@@ -409,9 +409,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
     uint32_t* umi_base = (uint32_t*)tab;                              // [nU+1] first slot of each barcode
     uint32_t* fmin = umi_base + (nU + 1);                             // [nF] fragment word: raw (P1) then state (R)
     uint32_t* worklist = fmin + nF;                                   // [nU] barcodes queued for the general calProb path
-    unsigned char* umi_flag = (unsigned char*)(worklist + nU);        // [nU]
+    uint32_t* bcinfo = worklist + nU;                                 // [nU] fragment count of a one-allele barcode still to score
+    unsigned char* umi_flag = (unsigned char*)(bcinfo + nU);          // [nU]
     // per 64 fragment slots, after the merge: which slots hold a fragment, which of those show the reference allele
-    unsigned long long* cmask = (unsigned long long*)(tab + ((4u * (uint32_t)(nU + 1) + 4u * (uint32_t)nF + 5u * (uint32_t)nU + 7u) & ~7u));
+    unsigned long long* cmask = (unsigned long long*)(tab + ((4u * (uint32_t)(nU + 1) + 4u * (uint32_t)nF + 9u * (uint32_t)nU + 7u) & ~7u));
 
     STAMP_INIT();
     // first step's reads are requested before the LDS image is initialised (HBM latency overlaps it)
@@ -888,6 +889,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
             unsigned long long live1;                                  // live slots of the last chunk touched
             uint32_t c1;
             const bool key = barcode_counts(u, nf, cr, live1, c1);
+            bcinfo[u] = 0xFFFFFFFFu;                                   // nothing to score in pass B (default)
             if (two_pass ? !umi_flag[u] : !key) continue;              // not a (kept) key of bcDict
             ++nb1;
             ufrag += nf; c3 += nf >= 3; c5 += nf >= 5; c7 += nf >= 7; c10 += nf >= 10;
@@ -903,6 +905,22 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                 worklist[atomicAdd(&H->misc[M_NCOMPLEX], 1u)] = (uint32_t)u;
                 continue;
             }
+            bcinfo[u] = (uint32_t)nf;
+        }
+        if (!two_pass) {
+            nb1 = (uint32_t)wave_add((int)nb1);
+            if (lane == 0 && nb1) atomicAdd(&H->misc[M_NBC], nb1);
+        }
+        __syncthreads();                                               // the queue of the general path is complete
+        STAMP(6);
+        // From here every wavefront works on its own, no barrier until the end of U: pass B scores the
+        // one-allele barcodes of the wave's threads from the table, then the wave takes its share of the queued
+        // barcodes - groups are handed out from the LAST thread down, so when the barcodes fill only the first
+        // wavefront(s) the two kinds of work run on different wavefronts at the same time.
+        for (int u = tid; u < nU; u += BLOCK) {
+            const uint32_t info = bcinfo[u];
+            if (info == 0xFFFFFFFFu) continue;
+            const int nf = (int)info;
             // one existing allele (the reference), three padded keys (:49-54): nk = 4
             const unsigned long long padmask = refa < 4 ? (0xFull & ~(1ull << refa)) : 0x7ull;
             const double pred0 = g_simple[2 * nf], predpad = g_simple[2 * nf + 1];
@@ -928,12 +946,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                 } else atomicAdd(&mtc[refa], 1u);
             }
         }
-        if (!two_pass) {
-            nb1 = (uint32_t)wave_add((int)nb1);
-            if (lane == 0 && nb1) atomicAdd(&H->misc[M_NBC], nb1);
-        }
-        // flush phase 0's lane accumulators (order-independent integer adds); phase 1 adds straight to LDS, so
-        // none of these registers stays live through its FP64 code
+        // flush the lane accumulators of passes A and B (order-independent integer adds); phase 1 adds straight
+        // to LDS, so none of these registers stays live through its FP64 code
+        if (tid - lane < nU) {                                         // (wave-uniform: the wave owns barcodes)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const long long p = wave_add64(pi_acc[a]);
@@ -954,13 +969,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
             atomicAdd(&H->misc[M_USEDFRAG], (uint32_t)ufrag);
             atomicOr(&H->misc[M_TOUCH_LO], touch_lo); atomicOr(&H->misc[M_TOUCH_HI], touch_hi);
         }
-        __syncthreads();
-        STAMP(6);
+        }
 
         // ---- phase 1: the queued barcodes (more than one allele, or not the reference), general path
         // (8 lanes per barcode here: few barcodes, short walks, and idle waves skip the phase)
         const int n_complex = SMC_ABLATE == 5 ? 0 : (int)H->misc[M_NCOMPLEX];   // 5: diagnostic, skips the general path
-        const int grp1 = tid / Gc, ngrp1 = BLOCK / Gc;
+        const int grp1 = (BLOCK - 1 - tid) / Gc, ngrp1 = BLOCK / Gc;   // groups from the last thread down
         for (int w = grp1; w < n_complex; w += ngrp1) {
             const int u = (int)worklist[w];
             int b0, b1, nf, cnt_ref;
@@ -1775,7 +1789,7 @@ static size_t host_hdr_bytes(int a_cap) {
     return sizeof(Hdr) + (size_t)a_cap * SMC_NT * 4 + (size_t)a_cap * 8 + (size_t)a_cap * 4 + (size_t)a_cap * 4 + 128 * 8;
 }
 static size_t table_bytes(const smc_locus& L) {
-    size_t b = 4 * ((size_t)L.n_umi + 1) + 4 * (size_t)L.n_frag + 5 * (size_t)L.n_umi;
+    size_t b = 4 * ((size_t)L.n_umi + 1) + 4 * (size_t)L.n_frag + 9 * (size_t)L.n_umi;
     b = (b + 7) & ~(size_t)7;
     b += 16 * (((size_t)L.n_frag + 63) / 64);             // chunk masks (live, live & reference allele)
     return (b + 15) & ~(size_t)15;
