@@ -769,8 +769,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         int bits = 32 - __clz(ubound);
         int shift = 58 - bits; if (shift > 48) shift = 48;
         const double fxscale = (double)(1ull << shift);
-        long long pi_acc[4] = {0, 0, 0, 0};
-        int mt_acc[4] = {0, 0, 0, 0}, st_acc[4] = {0, 0, 0, 0};
+        // lane accumulators of the table-scored barcodes: everything they add goes to the reference allele
+        // (fx0, consensus, strong) or equally to its padded keys (fxp)
+        long long acc_fx0 = 0, acc_fxp = 0;
+        int acc_mt = 0, acc_st = 0;
         int c3 = 0, c5 = 0, c7 = 0, c10 = 0, ufrag = 0;
         uint32_t touch_lo = 0, touch_hi = 0;
         const double pne = 1.0 - 3e-5;                                 // pcr_no_error, :20
@@ -897,7 +899,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                 touch_lo |= 0xFu;                                      // finalDict gets A,T,G,C (+ -0.0)
                 if (nf == 1) {                                         // tie -> single-fragment rule, :521-523
                     const int a = (int)KEY_ALLELE(fmin[64u * c1 + (uint32_t)(__ffsll((long long)live1) - 1)]);
-                    if (a < 4) mt_acc[a]++; else atomicAdd(&mtc[a], 1u);
+                    atomicAdd(&mtc[a], 1u);
                 }
                 continue;
             }
@@ -917,46 +919,42 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         // one-allele barcodes of the wave's threads from the table, then the wave takes its share of the queued
         // barcodes - groups are handed out from the LAST thread down, so when the barcodes fill only the first
         // wavefront(s) the two kinds of work run on different wavefronts at the same time.
+        bool scored = false;
         for (int u = tid; u < nU; u += BLOCK) {
             const uint32_t info = bcinfo[u];
             if (info == 0xFFFFFFFFu) continue;
             const int nf = (int)info;
             // one existing allele (the reference), three padded keys (:49-54): nk = 4
-            const unsigned long long padmask = refa < 4 ? (0xFull & ~(1ull << refa)) : 0x7ull;
             const double pred0 = g_simple[2 * nf], predpad = g_simple[2 * nf + 1];
-            const long long fx0 = to_fx(pred0, fxscale), fxp = to_fx(predpad, fxscale);
-            if (refa >= 4) atomicAdd(&pifx[refa], (unsigned long long)fx0);
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                if (a == refa) pi_acc[a] += fx0;
-                else if ((padmask >> a) & 1ull) pi_acc[a] += fxp;
-            }
-            const unsigned long long uq = (1ull << refa) | padmask;
-            touch_lo |= (uint32_t)uq; touch_hi |= (uint32_t)(uq >> 32);
+            acc_fx0 += to_fx(pred0, fxscale);
+            acc_fxp += to_fx(predpad, fxscale);
+            scored = true;
             if (pred0 > predpad) {                                     // unique maximum (:514-519)
-                const bool str = pred0 > P.smt;
-                if (refa < 4) {
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) if (a == refa) { mt_acc[a]++; st_acc[a] += str; }
-                } else { atomicAdd(&mtc[refa], 1u); if (str) atomicAdd(&strong[refa], 1u); }
+                ++acc_mt;
+                acc_st += pred0 > P.smt;
             } else if (nf == 1) {                                      // :521-523
-                if (refa < 4) {
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) if (a == refa) mt_acc[a]++;
-                } else atomicAdd(&mtc[refa], 1u);
+                ++acc_mt;
             }
         }
         // flush the lane accumulators of passes A and B (order-independent integer adds); phase 1 adds straight
         // to LDS, so none of these registers stays live through its FP64 code
         if (tid - lane < nU) {                                         // (wave-uniform: the wave owns barcodes)
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const long long p = wave_add64(pi_acc[a]);
-            const int m = wave_add(mt_acc[a]), s = wave_add(st_acc[a]);
-            if (lane == 0) {
-                if (p) atomicAdd(&pifx[a], (unsigned long long)p);
-                if (m) atomicAdd(&mtc[a], (uint32_t)m);
-                if (s) atomicAdd(&strong[a], (uint32_t)s);
+        {
+            // one existing allele (the reference), three padded keys (:49-54): nk = 4
+            const unsigned long long padmask = refa < 4 ? (0xFull & ~(1ull << refa)) : 0x7ull;
+            const long long s0 = wave_add64(acc_fx0), sp = wave_add64(acc_fxp);
+            const int m = wave_add(acc_mt), st = wave_add(acc_st);
+            if (BAL(scored)) {
+                const unsigned long long uq = (1ull << refa) | padmask;
+                touch_lo |= (uint32_t)uq; touch_hi |= (uint32_t)(uq >> 32);
+            }
+            if (lane == 0 && refa < 64) {
+                if (s0) atomicAdd(&pifx[refa], (unsigned long long)s0);
+                if (sp)
+                    for (int a = 0; a < 4; ++a)
+                        if ((padmask >> a) & 1ull) atomicAdd(&pifx[a], (unsigned long long)sp);
+                if (m) atomicAdd(&mtc[refa], (uint32_t)m);
+                if (st) atomicAdd(&strong[refa], (uint32_t)st);
             }
         }
         c3 = wave_add(c3); c5 = wave_add(c5);
