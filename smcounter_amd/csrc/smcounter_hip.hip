@@ -428,14 +428,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         // (only the first lane of a wavefront fetches them; the others take them from their neighbour lane)
         if (lane == 0 && tid > 0) { pf2 = frag2[2 * tid - 1]; pm1 = ((const uint32_t*)meta4)[4 * tid - 1]; }
     }
-    // quality -> error-probability table: requested now, parked in registers, stored to LDS after the
-    // scan (its first reader is the calProb phase), so no phase waits on this load
-    double lut_reg[(LUT_N + BLOCK - 1) / BLOCK];
-#pragma unroll
-    for (int t = 0; t < (LUT_N + BLOCK - 1) / BLOCK; ++t) {
-        const int i = tid + t * BLOCK;
-        lut_reg[t] = i < LUT_N ? g_lut[i] : 0.0;
-    }
     // ---- S0: init
     uint32_t b0_early = 0xFFFFFFFFu;
     {
@@ -443,6 +435,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         const int nz = (int)((sizeof(Hdr) + a_cap * 64) / 4);
         for (int i = tid; i < nz; i += BLOCK) z[i] = 0;
         for (int i = tid; i < nF; i += BLOCK) fmin[i] = 0u;
+        // quality -> error-probability table (read by the calProb phase; 'unpaired' -> 0.1, smCounter.py:65-68)
+        for (int i = tid; i < LUT_N; i += BLOCK) lut[i] = i == (int)PIDX_UNPAIRED ? 0.1 : g_lut[i];
         // first read of every barcode (+ closing entry); S2 turns it into the first fragment slot
         const uint32_t* ustart = g_umi_start + L.umi_off;
         for (int i = tid; i <= nU; i += BLOCK) umi_base[i] = ustart[i] & ~SMC_USTART_DROPPED;
@@ -593,11 +587,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         if (lane == 0 && n_inc_s) atomicAdd(&H->misc[M_NINC], n_inc_s);
         if (err_m && lane == 0) H->misc[M_ERR] = 1;
         if (ovf_any && lane == 0) H->misc[M_NEEDFIX] = 1;
-#pragma unroll
-        for (int t = 0; t < (LUT_N + BLOCK - 1) / BLOCK; ++t) {
-            const int i = tid + t * BLOCK;
-            if (i < LUT_N) lut[i] = i == (int)PIDX_UNPAIRED ? 0.1 : lut_reg[t];
-        }
     }
     __syncthreads();
     STAMP(1);
