@@ -55,7 +55,7 @@ struct Hdr {
 };
 enum {
     M_NINC = 0,   // included reads
-    M_RESOLVED,   // reads accounted for by <=2-read fragments
+    M_SPARE0,
     M_ERR,
     M_NBC,        // barcodes with an included read
     M_ALLMT,
@@ -156,44 +156,11 @@ __device__ __forceinline__ long long wave_add64(long long v) {
     return t;
 }
 
-// block-wide exclusive prefix sum over arr[0..n) in place; returns the total (in all threads).
-template <int BLOCK>
-__device__ uint32_t block_exclusive_scan(uint32_t* arr, int n, uint32_t* tmp /*>= 32 u32 in LDS*/) {
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    constexpr int NW = BLOCK / WAVE;
-    uint32_t carry = 0;
-    for (int base = 0; base < n; base += BLOCK) {
-        int i = base + tid;
-        uint32_t v = i < n ? arr[i] : 0u;
-        uint32_t inc = v;
-        for (int d = 1; d < WAVE; d <<= 1) {
-            uint32_t t = __shfl_up((int)inc, d);
-            if (lane >= d) inc += t;
-        }
-        if (lane == 63) tmp[wid] = inc;
-        __syncthreads();
-        uint32_t woff = 0, tot = 0;
-        for (int w = 0; w < NW; ++w) {
-            uint32_t t = tmp[w];
-            if (w < wid) woff += t;
-            tot += t;
-        }
-        if (i < n) arr[i] = carry + woff + inc - v;
-        carry += tot;
-        __syncthreads();
-    }
-    return carry;
-}
-
-__device__ __forceinline__ uint32_t make_key(int idx, int allele, int bq) {
-    return ((uint32_t)idx << 14) | ((uint32_t)allele << 8) | (uint32_t)bq;
-}
 #define KEY_ALLELE(k) (((k) >> 8) & 63u)
-#define KEY_BQ(k) ((k) & 255u)
 // fragment state word (after resolve), kept in fmin[]: present | allele << 8 | probability index.
 // The index is the merged quality of a 'Paired' fragment (error prob 10^(-q/10)) or PIDX_UNPAIRED
-// for a single read (prob forced to 0.1, smCounter.py:67-68); qualities >= 127 (never produced by
-// a sequencer) take a slow path through the global table.
+// for a single read (prob forced to 0.1, smCounter.py:67-68); qualities are <= 126 by the batch contract
+// (a BAM holds 0..93) and clamped to that.
 #define ST_PRESENT 0x80000000u
 #define ST_PAIRED 0x40000000u
 // raw fragment word (P1): first read in bits 0-13 (allele << 8 | quality), second in 14-27
@@ -366,9 +333,6 @@ __device__ __forceinline__ void finish_row(smc_row* R, const smc_locus& L, int l
 // ------------------------------------------------------------------------------------------
 #ifndef SMC_ABLATE
 #define SMC_ABLATE 0   // diagnostic builds: return after phase N (timing only, rows are garbage)
-#endif
-#ifndef SMC_G_FRAGS
-#define SMC_G_FRAGS 24
 #endif
 // 6 waves per SIMD (<= 80 VGPRs; LDS allows 14 workgroups of 2 waves per CU on the C3 shape): measured best of 4..8
 #ifndef SMC_WAVES_PER_EU
