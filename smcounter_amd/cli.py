@@ -17,6 +17,7 @@ import os
 import sys
 
 from . import bamio, bedops, fasta, postfilter, runlog, vc, writers
+from . import dist as smcdist
 from .params import VcParams
 
 
@@ -52,6 +53,22 @@ def build_parser() -> argparse.ArgumentParser:
     return p
 
 
+def call_shard(args, params: VcParams, loci, device: int):
+    """The per-locus rows (strings, smCounter.py:599) of a run of loci: BAM decode -> device batches -> kernels."""
+    from .engine import Engine
+    ref = fasta.FastaFile(args.refGenome)
+    eng = Engine(device)
+    output = []
+    if os.environ.get("SMC_BAM_DECODER", "native") == "python":       # readable decoder, same batches
+        batches = bamio.iter_pileup_batches(bamio.BamFile(args.bamFile), ref, loci, max_reads=args.batchReads)
+    else:
+        batches = bamio.iter_device_batches_native(args.bamFile, ref, loci, params, max_reads=args.batchReads)
+    for first, pb in batches:
+        output.extend(vc.vc_batch(pb, params, ref, eng=eng))
+    eng.close()
+    return output
+
+
 def main(args) -> int:
     """Same contract as the reference's main(args): accepts a Namespace or a dict of argument values,
     returns the PI threshold used (smCounter.py:909)."""
@@ -72,19 +89,19 @@ def main(args) -> int:
     params = VcParams(minBQ=args.minBQ, minMQ=args.minMQ, mtDepth=args.mtDepth, rpb=args.rpb, hpLen=args.hpLen,
                       mismatchThr=args.mismatchThr, mtDrop=args.mtDrop, maxMT=args.maxMT, primerDist=args.primerDist)
     loc_list = bedops.expand_loci(args.bedTarget)
-    ref = fasta.FastaFile(args.refGenome)
-    from .engine import Engine
-    eng = Engine(args.device)
-    output = []
-    if os.environ.get("SMC_BAM_DECODER", "native") == "python":       # readable decoder, same batches
-        bam = bamio.BamFile(args.bamFile)
-        batches = bamio.iter_pileup_batches(bam, ref, loc_list, max_reads=args.batchReads)
-    else:
-        batches = bamio.iter_device_batches_native(args.bamFile, ref, loc_list, params, max_reads=args.batchReads)
-    for first, pb in batches:
-        output.extend(vc.vc_batch(pb, params, ref, eng=eng))
-    eng.close()
-    vc.raise_on_exception(output, loc_list)
+    # One process per GPU when launched through torch.distributed.run: rank r calls a contiguous range of the
+    # ordered locus list (loci share nothing, smCounter.py:683-685) on GPU LOCAL_RANK, rank 0 gathers the rows
+    # in submission order and writes the files.
+    rank, local_rank, world = smcdist.init_from_env()
+    lo, hi = smcdist.shard_range(len(loc_list), rank, world)
+    output = call_shard(args, params, loc_list[lo:hi], local_rank if world > 1 else args.device)
+    vc.raise_on_exception(output, loc_list[lo:hi])
+    if world > 1:
+        output = smcdist.gather_strings(output, dst=0)
+        import torch.distributed as tdist
+        tdist.barrier()
+        if rank != 0:
+            return writers.pi_threshold(args.mtDepth, args.threshold)
 
     print("begin variant filtering and output")
     have_rep = [b for b in (args.bedTandemRepeats, args.bedRepeatMaskerSubset) if b and os.path.exists(b)]

@@ -58,3 +58,37 @@ def gatherv_rows(rows, counts: Sequence[int], row_bytes: int, dst: int = 0):
     if rank != dst:
         return None
     return torch.cat([g[:counts[r] * row_bytes] for r, g in enumerate(glist)])
+
+
+def gather_strings(local: Sequence[str], dst: int = 0):
+    """Row strings of every rank, concatenated in rank order on `dst` (None elsewhere): the distributed
+    command line's hand-over of its 45-field rows (indel alleles make them variable-length) to the writers."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    parts = [None] * world if rank == dst else None
+    dist.gather_object(list(local), parts, dst=dst)
+    if rank != dst:
+        return None
+    return [s for part in parts for s in part]
+
+
+def init_from_env():
+    """(rank, local_rank, world) of a `python -m torch.distributed.run` launch, process group initialised
+    (`nccl` = RCCL when a GPU is visible, else `gloo`; SMC_DIST_BACKEND overrides); (0, 0, 1) when not launched
+    that way."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 0, 1
+    import torch
+    import torch.distributed as dist
+    rank, local_rank = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("SMC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if not dist.is_initialized():
+        if backend == "nccl":
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    return rank, local_rank, world

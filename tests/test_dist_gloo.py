@@ -59,3 +59,69 @@ def test_two_rank_gather_restores_submission_order():
     P = synth.params_for(cfg)
     want = oracle_lib.call_batch(synth.generate_native(cfg, 0, n_loci, P, nthreads=1), abi.c_params(P), abi.ROW_DTYPE)
     assert got.tobytes() == want.tobytes()
+
+
+def _cli_worker(rank, world, port, tmp, q):
+    """One rank of the distributed command line; the GPU call is swapped for the CPU restatement (this test is
+    about sharding, the string gather and the writers on rank 0)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world), SMC_DIST_BACKEND="gloo")
+    from smcounter_amd import abi, bamio, cli, fasta, rows
+    import oracle_lib
+
+    def cpu_call_shard(args, params, loci, device):
+        ref = fasta.FastaFile(args.refGenome)
+        out = []
+        for _, db in bamio.iter_device_batches_native(args.bamFile, ref, loci, params, max_reads=args.batchReads):
+            R = oracle_lib.call_batch(db, abi.c_params(params), abi.ROW_DTYPE)
+            out.extend(rows.format_rows(R, db, params, ref))
+        return out
+    cli.call_shard = cpu_call_shard
+    prefix = os.path.join(tmp, "dist")
+    thr = cli.main(dict(outPrefix=prefix, bamFile=os.path.join(tmp, "case.bam"), bedTarget=os.path.join(tmp, "case.bed"),
+                        mtDepth=12, rpb=3.0, hpLen=8, refGenome=os.path.join(tmp, "case.fa"), threshold=10,
+                        batchReads=300))
+    if rank == 0:
+        q.put(thr)
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_command_line_writes_the_single_process_files(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bam_fixture
+    from smcounter_amd import abi, bamio, bedops, fasta, postfilter, rows, writers
+    from smcounter_amd.params import VcParams
+    import oracle_lib
+    case = bam_fixture.make_case(str(tmp_path))
+    for k, name in (("bam", "case.bam"), ("bed", "case.bed"), ("fasta", "case.fa")):
+        os.replace(case[k], str(tmp_path / name))
+    if os.path.exists(case["fasta"] + ".fai"):
+        os.replace(case["fasta"] + ".fai", str(tmp_path / "case.fa.fai"))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cli_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    assert q.get(timeout=240) == 10
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # single-process expectation
+    P = VcParams(mtDepth=12, rpb=3.0, hpLen=8)
+    fa = fasta.FastaFile(str(tmp_path / "case.fa"))
+    loci = bedops.expand_loci(str(tmp_path / "case.bed"))
+    want = []
+    for _, db in bamio.iter_device_batches_native(str(tmp_path / "case.bam"), fa, loci, P):
+        want.extend(rows.format_rows(oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE), db, P, fa))
+    want = postfilter.apply_repeat_filters(want, {}, {})
+    got = open(str(tmp_path / "dist.smCounter.all.txt")).read().split("\n")[1:-1]
+    assert got == want and len(got) == len(loci)
+    assert os.path.getsize(str(tmp_path / "dist.smCounter.cut.vcf")) > 0
