@@ -490,6 +490,9 @@ def iter_pileup_batches(bam: BamFile, fasta, loci: Sequence[Tuple[str, str]], ma
 # native decoder (csrc/smc_bam.cpp): same batches, two orders of magnitude faster
 # ------------------------------------------------------------------------------------------------
 _NATIVE = None
+import ctypes as _C
+# allocation callback of smc_bam_planes: (ctx, n_slots, n_loci, void* out[5])
+_PLANES_ALLOC = _C.CFUNCTYPE(None, _C.c_void_p, _C.c_int64, _C.c_int64, _C.POINTER(_C.c_void_p))
 
 
 def _native_lib():
@@ -508,11 +511,12 @@ def _native_lib():
         lib.smc_bam_keys_len.restype = C.c_int64
         lib.smc_bam_copy.argtypes = [C.c_void_p] * 18
         lib.smc_bam_planes.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int64, C.c_double,
-                                       C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.POINTER(C.c_int64)] * 3
+                                       C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, _PLANES_ALLOC, C.c_void_p] \
+            + [C.POINTER(C.c_int64)] * 3
         lib.smc_bam_ds_info.argtypes = [C.c_void_p]
         lib.smc_bam_ds_info.restype = C.c_char_p
         lib.smc_bam_planes.restype = C.c_int64
-        lib.smc_bam_planes_copy.argtypes = [C.c_void_p] * 9
+        lib.smc_bam_planes_copy.argtypes = [C.c_void_p] * 4
         _NATIVE = lib
     return _NATIVE
 
@@ -585,21 +589,28 @@ class NativeBam(object):
         from .features import LOCUS_DTYPE, PileupError
         done, n_slots, n_us = C.c_int64(0), C.c_int64(0), C.c_int64(0)
         refb = refseq.encode().ljust(hi - lo, b"\0")
+        got = {}
+
+        def alloc(ctx, ns, nl_, out):                    # the library writes straight into these arrays
+            got["planes"] = [np.empty(ns, np.uint32) for _ in range(4)]
+            got["loci"] = np.empty(nl_, LOCUS_DTYPE)
+            for k in range(4):
+                out[k] = got["planes"][k].ctypes.data
+            out[4] = got["loci"].ctypes.data
+        cb = _PLANES_ALLOC(alloc)
         n = self._lib.smc_bam_planes(self._h, chrom.encode(), lo, hi, max_reads, float(params.mismatchThr), refb,
-                                     int(nthreads), int(params.ds), int(params.minBQ), int(params.minMQ),
+                                     int(nthreads), int(params.ds), int(params.minBQ), int(params.minMQ), cb, None,
                                      C.byref(done), C.byref(n_slots), C.byref(n_us))
         if n < 0:
             msg = self._lib.smc_bam_error(self._h).decode()
             raise (PileupError if n <= -6 else BamError)(msg)
         nl = done.value
-        planes = [np.empty(n_slots.value, np.uint32) for _ in range(4)]
+        planes, loci = got["planes"], got["loci"]
         ustart = np.empty(n_us.value, np.uint32)
-        loci = np.empty(nl, LOCUS_DTYPE)
         n_keys = np.empty(nl, np.int32)
         keys = C.create_string_buffer(max(1, self._lib.smc_bam_keys_len(self._h)))
         ptr = lambda a: a.ctypes.data_as(C.c_void_p)
-        self._lib.smc_bam_planes_copy(self._h, *[ptr(p) for p in planes], ptr(ustart), ptr(loci), ptr(n_keys),
-                                      C.cast(keys, C.c_void_p))
+        self._lib.smc_bam_planes_copy(self._h, ptr(ustart), ptr(n_keys), C.cast(keys, C.c_void_p))
         # the reference's down-sampling (smCounter.py:496-498) on loci over the barcode cap
         info = self._lib.smc_bam_ds_info(self._h).decode()
         if info:
@@ -685,8 +696,7 @@ def iter_device_batches_native(path: str, fasta, loci: Sequence[Tuple[str, str]]
             refs += [run_ref[k:k + 1] for k in range(nl)]
             tables += tb
             i += nl
-        yield first, DeviceBatch(loci=np.concatenate(LC), meta=np.concatenate(P[0]), umi=np.concatenate(P[1]),
-                                 frag=np.concatenate(P[2]), dist=np.concatenate(P[3]),
-                                 umi_start=np.concatenate(US), chrom=chroms, pos=np.array(poss, np.int64),
-                                 ref=refs, alleles=tables)
+        cat = lambda parts: parts[0] if len(parts) == 1 else np.concatenate(parts)
+        yield first, DeviceBatch(loci=cat(LC), meta=cat(P[0]), umi=cat(P[1]), frag=cat(P[2]), dist=cat(P[3]),
+                                 umi_start=cat(US), chrom=chroms, pos=np.array(poss, np.int64), ref=refs, alleles=tables)
     bam.close()

@@ -41,6 +41,7 @@ struct Aln {
 struct Bam {
     FILE* fh = nullptr;
     std::string err;
+    int io_threads = 1;                // threads inflating BGZF blocks in collect_reads
     std::vector<std::string> ref_names;
     std::vector<int32_t> ref_lens;
     std::vector<std::vector<uint64_t>> lin;   // BAI linear index per reference
@@ -57,8 +58,7 @@ struct Bam {
     std::string keys;                  // allele keys beyond the six fixed ones, '\n' separated per locus, loci '\0'
     std::vector<int32_t> n_keys;       // per locus
     // last smc_bam_planes result (keys / n_keys shared with the pileup result)
-    std::vector<uint32_t> p_meta, p_umi, p_frag, p_dist, p_umi_start;
-    std::vector<smc_locus> p_loci;
+    std::vector<uint32_t> p_umi_start;
     std::string ds_info;               // loci over the barcode cap: "<locus>\t<u>:<barcode>\t...\n", barcodes by first included read
 
     bool load_block(uint64_t coff) {
@@ -106,12 +106,8 @@ struct Bam {
 
 const char SEQ_CODE[] = "=ACMGRSVTWYHKDBN";
 
-bool parse_record(Bam& b, Aln& a, int32_t& tid) {
-    int32_t bs;
-    if (b.read(&bs, 4) != 4) return false;
-    std::vector<uint8_t> r((size_t)bs);
-    if (b.read(r.data(), r.size()) != r.size()) return false;
-    const uint8_t* p = r.data();
+// one alignment record (without its block_size word) -> Aln
+void parse_body(const uint8_t* p, size_t r_size, Aln& a, int32_t& tid) {
     int32_t pos, l_seq;
     memcpy(&tid, p, 4); memcpy(&pos, p + 4, 4);
     const unsigned l_name = p[8];
@@ -132,7 +128,7 @@ bool parse_record(Bam& b, Aln& a, int32_t& tid) {
     a.qual.assign(p + o, p + o + l_seq);
     o += l_seq;
     a.nm = 0; a.has_nm = 0;
-    while (o + 3 <= r.size()) {   // aux: find NM (smCounter.py:329-334)
+    while (o + 3 <= r_size) {   // aux: find NM (smCounter.py:329-334)
         const char t0 = p[o], t1 = p[o + 1], ty = p[o + 2];
         o += 3;
         size_t sz = 0;
@@ -140,7 +136,7 @@ bool parse_record(Bam& b, Aln& a, int32_t& tid) {
             case 'A': case 'c': case 'C': sz = 1; break;
             case 's': case 'S': sz = 2; break;
             case 'i': case 'I': case 'f': sz = 4; break;
-            case 'Z': case 'H': { while (o < r.size() && p[o]) ++o; ++o; continue; }
+            case 'Z': case 'H': { while (o < r_size && p[o]) ++o; ++o; continue; }
             case 'B': {
                 const char sub = p[o];
                 uint32_t cnt; memcpy(&cnt, p + o + 1, 4);
@@ -148,7 +144,7 @@ bool parse_record(Bam& b, Aln& a, int32_t& tid) {
                 o += 5 + (size_t)cnt * es;
                 continue;
             }
-            default: o = r.size(); continue;
+            default: o = r_size; continue;
         }
         if (t0 == 'N' && t1 == 'M' && ty != 'A' && ty != 'f') {
             int64_t v = 0;
@@ -165,8 +161,86 @@ bool parse_record(Bam& b, Aln& a, int32_t& tid) {
     int32_t e = pos;
     for (uint32_t c : a.cigar) { const unsigned op = c & 15; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) e += (int32_t)(c >> 4); }
     a.end = e;
-    return true;
 }
+
+// Record stream over consecutive BGZF blocks starting at a virtual offset: blocks are read from the file in
+// batches and inflated by `nthreads` threads (each block is an independent deflate stream), records are then
+// parsed in place.
+struct BlockStream {
+    Bam& b;
+    int nthreads;
+    uint64_t next_coff;
+    std::vector<uint8_t> data;     // inflated bytes not yet consumed, from `pos`
+    size_t pos = 0;
+    bool eof = false;
+    bool keep = false;             // keep consumed bytes (record offsets stay valid)
+    BlockStream(Bam& bam, uint64_t voff, int nt, bool keep_all = false) : b(bam), nthreads(nt < 1 ? 1 : nt), next_coff(voff >> 16), keep(keep_all) {
+        refill();
+        pos = (size_t)(voff & 0xFFFF);
+        if (pos > data.size()) pos = data.size();
+    }
+    bool refill() {
+        if (eof) return false;
+        if (!keep) { data.erase(data.begin(), data.begin() + (long)pos); pos = 0; }
+        const int batch = nthreads > 1 ? 8 * nthreads : 4;
+        struct Raw { std::vector<uint8_t> comp; size_t c0, clen; uint32_t isize; size_t out_off; };
+        std::vector<Raw> raws;
+        if (fseeko(b.fh, (off_t)next_coff, SEEK_SET) != 0) { eof = true; return false; }
+        size_t total = 0;
+        for (int k = 0; k < batch; ++k) {
+            uint8_t hdr[18];
+            if (fread(hdr, 1, 18, b.fh) != 18) { eof = true; break; }
+            if (hdr[0] != 31 || hdr[1] != 139 || hdr[12] != 'B' || hdr[13] != 'C') { b.err = "not a BGZF block"; eof = true; break; }
+            const unsigned xlen = hdr[10] | (hdr[11] << 8), bsize = (hdr[16] | (hdr[17] << 8)) + 1;
+            Raw r;
+            r.comp.resize(bsize - 18);
+            if (fread(r.comp.data(), 1, r.comp.size(), b.fh) != r.comp.size()) { b.err = "truncated BGZF block"; eof = true; break; }
+            r.c0 = xlen - 6; r.clen = r.comp.size() - r.c0 - 8;
+            const size_t e = r.comp.size();
+            r.isize = r.comp[e - 4] | (r.comp[e - 3] << 8) | (r.comp[e - 2] << 16) | ((uint32_t)r.comp[e - 1] << 24);
+            r.out_off = total; total += r.isize;
+            next_coff += bsize;
+            raws.push_back(std::move(r));
+        }
+        if (raws.empty()) return false;
+        const size_t base = data.size();
+        data.resize(base + total);
+        std::atomic<int> bad(0), next(0);
+        auto work = [&]() {
+            for (int i = next.fetch_add(1); i < (int)raws.size(); i = next.fetch_add(1)) {
+                Raw& r = raws[(size_t)i];
+                if (!r.isize) continue;
+                z_stream zs;
+                memset(&zs, 0, sizeof zs);
+                if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; continue; }
+                zs.next_in = r.comp.data() + r.c0; zs.avail_in = (uInt)r.clen;
+                zs.next_out = data.data() + base + r.out_off; zs.avail_out = r.isize;
+                if (inflate(&zs, Z_FINISH) != Z_STREAM_END) bad = 1;
+                inflateEnd(&zs);
+            }
+        };
+        const int T = std::min<int>(nthreads, (int)raws.size());
+        if (T <= 1) work();
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; ++t) th.emplace_back(work);
+            for (auto& x : th) x.join();
+        }
+        if (bad.load()) { b.err = "inflate failed"; eof = true; return false; }
+        return true;
+    }
+    // next record body (without block_size), contiguous in memory; nullptr at the end of the file
+    const uint8_t* next_record(size_t& n) {
+        while (data.size() - pos < 4) if (!refill()) return nullptr;
+        int32_t bs;
+        memcpy(&bs, data.data() + pos, 4);
+        while (data.size() - pos < 4 + (size_t)bs) if (!refill()) return nullptr;
+        const uint8_t* p = data.data() + pos + 4;
+        pos += 4 + (size_t)bs;
+        n = (size_t)bs;
+        return p;
+    }
+};
 
 // Mapped alignments overlapping [start0, end0) on `chrom`, in file order, with run-wide barcode / fragment ids
 // and the per-read CIGAR summaries.  Returns 0, or the negative error code of smc_bam_pileup.
@@ -183,12 +257,49 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::
             while (w >= 0 && iv[(size_t)w] == 0) --w;
             if (w >= 0) voff = iv[(size_t)w];
         }
-        b.seek(voff);
-        Aln a;
-        int32_t rt;
-        while (parse_record(b, a, rt)) {
-            if (rt < 0 || rt > tid || (rt == tid && a.pos >= end0)) break;
-            if (rt < tid || (a.flag & 4) || a.cigar.empty()) continue;
+        b.err.clear();
+        // 1. inflate (threads) and find the record boundaries up to the first alignment starting at or after end0
+        BlockStream bs(b, voff, b.io_threads, true);
+        std::vector<std::pair<size_t, size_t>> recs;    // (offset of the body in bs.data, size)
+        for (;;) {
+            size_t rn;
+            const uint8_t* rp = bs.next_record(rn);
+            if (!rp) break;
+            int32_t rt, rpos;
+            memcpy(&rt, rp, 4); memcpy(&rpos, rp + 4, 4);
+            if (rt < 0 || rt > tid || (rt == tid && rpos >= end0)) break;
+            if (rt < tid) continue;
+            recs.emplace_back((size_t)(rp - bs.data.data()), rn);
+        }
+        // 2. parse them (threads), 3. filter and intern barcode / read ids in file order
+        std::vector<Aln> parsed(recs.size());
+        {
+            const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)b.io_threads, recs.size() / 256 + 1));
+            auto work = [&](int t) {
+                const size_t lo = recs.size() * (size_t)t / (size_t)T, hi = recs.size() * (size_t)(t + 1) / (size_t)T;
+                int32_t rt;
+                for (size_t i = lo; i < hi; ++i) {
+                    Aln& a = parsed[i];
+                    parse_body(bs.data.data() + recs[i].first, recs[i].second, a, rt);
+                    a.n_ind = 0; a.qalen = 0;
+                    for (uint32_t c : a.cigar) {
+                        const unsigned op = c & 15;
+                        if (op == 1 || op == 2) a.n_ind += c >> 4;
+                        if (op == 0 || op == 1 || op == 7 || op == 8) a.qalen += c >> 4;
+                    }
+                    a.left_sp = (!a.cigar.empty() && (a.cigar[0] & 15) == 4) ? (a.cigar[0] >> 4) : 0u;
+                    a.oflag = (uint8_t)(((a.flag & 0x40) ? 1 : 0) | ((a.flag & 0x80) ? 2 : 0) | ((a.flag & 0x10) ? 4 : 0) | (a.has_nm ? 8 : 0));
+                }
+            };
+            if (T == 1) work(0);
+            else {
+                std::vector<std::thread> th;
+                for (int t = 0; t < T; ++t) th.emplace_back(work, t);
+                for (auto& x : th) x.join();
+            }
+        }
+        for (Aln& a : parsed) {
+            if ((a.flag & 4) || a.cigar.empty()) continue;
             if (a.end <= start0) continue;
             // qname -> barcode / read id (smCounter.py:320-325): <readid...>:<UMI>:<x>
             const std::string& qn = a.qname;
@@ -199,16 +310,9 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::
             const std::string bc = qn.substr(c2 + 1, c1 - c2 - 1);
             a.bc_gid = bc_ids.emplace(bc, (int)bc_ids.size()).first->second;
             a.pair_gid = pair_ids.emplace(bc + "\x01" + qn.substr(0, c2), (int)pair_ids.size()).first->second;
-            a.n_ind = 0; a.qalen = 0;
-            for (uint32_t c : a.cigar) {
-                const unsigned op = c & 15;
-                if (op == 1 || op == 2) a.n_ind += c >> 4;
-                if (op == 0 || op == 1 || op == 7 || op == 8) a.qalen += c >> 4;
-            }
-            a.left_sp = ((a.cigar[0] & 15) == 4) ? (a.cigar[0] >> 4) : 0u;
-            a.oflag = (uint8_t)(((a.flag & 0x40) ? 1 : 0) | ((a.flag & 0x80) ? 2 : 0) | ((a.flag & 0x10) ? 4 : 0) | (a.has_nm ? 8 : 0));
-            reads.push_back(a);
+            reads.push_back(std::move(a));
         }
+        if (!b.err.empty()) return -2;                  // corrupt / truncated BGZF
     }
     n_bc = (int)bc_ids.size(); n_pair = (int)pair_ids.size();
     if (bc_names) { bc_names->assign(bc_ids.size(), std::string()); for (const auto& kv : bc_ids) (*bc_names)[(size_t)kv.second] = kv.first; }
@@ -410,11 +514,16 @@ void smc_bam_copy(void* h, uint32_t* umi, uint32_t* frag, uint8_t* flag, uint8_t
 // ds > 0: for every locus with more barcodes than ds, the barcodes that own an included read (bq >= min_bq or inside a
 // deletion, mapq >= min_mq, mismatches within mismatch_thr: incCond, smCounter.py:378) are listed with their text in
 // order of that read (smc_bam_ds_info) - the host needs them for the reference's down-sampling (:496-498).
+// The planes and the descriptors are written straight into caller memory: once the sizes are known `alloc(ctx, n_slots,
+// n_loci, out)` is called and must fill out[0..3] with four uint32[n_slots] buffers (meta, umi, frag, dist) and out[4]
+// with an smc_locus[n_loci] buffer (uninitialised memory is fine: every entry, padding included, is written).
+typedef void (*smc_planes_alloc)(void* ctx, int64_t n_slots, int64_t n_loci, void** out);
 int64_t smc_bam_planes(void* h, const char* chrom, int64_t start0, int64_t end0, int64_t max_reads, double mismatch_thr,
-                       const char* refseq, int nthreads, int ds, int min_bq, int min_mq, int64_t* n_loci_done,
-                       int64_t* n_slots, int64_t* n_umi_start) {
+                       const char* refseq, int nthreads, int ds, int min_bq, int min_mq, smc_planes_alloc alloc,
+                       void* alloc_ctx, int64_t* n_loci_done, int64_t* n_slots, int64_t* n_umi_start) {
     Bam& b = *(Bam*)h;
     b.keys.clear(); b.n_keys.clear(); b.ds_info.clear();
+    b.io_threads = nthreads;
     *n_loci_done = *n_slots = *n_umi_start = 0;
     std::vector<Aln> reads;
     int n_bc = 0, n_pair = 0;
@@ -442,8 +551,12 @@ int64_t smc_bam_planes(void* h, const char* chrom, int64_t start0, int64_t end0,
         if (total >= max_reads) break;
     }
     const int64_t slots = off.back();
-    b.p_meta.assign((size_t)slots, 0); b.p_umi.assign((size_t)slots, 0); b.p_frag.assign((size_t)slots, 0); b.p_dist.assign((size_t)slots, 0);
-    b.p_loci.assign((size_t)nl, smc_locus{});
+    void* bufs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    alloc(alloc_ctx, slots, nl, bufs);
+    uint32_t* const pm = (uint32_t*)bufs[0]; uint32_t* const pu = (uint32_t*)bufs[1];
+    uint32_t* const pf = (uint32_t*)bufs[2]; uint32_t* const pd = (uint32_t*)bufs[3];
+    smc_locus* const ploci = (smc_locus*)bufs[4];
+    if ((slots && (!pm || !pu || !pf || !pd)) || (nl && !ploci)) { b.err = "smc_bam_planes: allocation callback returned no memory"; return -9; }
     b.n_keys.assign((size_t)nl, 0);
     const auto t_a = std::chrono::steady_clock::now();
     const int T = (int)std::max<int64_t>(1, std::min<int64_t>(nthreads, nl));
@@ -523,9 +636,10 @@ int64_t smc_bam_planes(void* h, const char* chrom, int64_t start0, int64_t end0,
             const size_t o = (size_t)off[(size_t)l];
             for (size_t i = 0; i < n; ++i) {
                 const size_t d = o + (size_t)slot_cnt[c_frag[i]]++;
-                b.p_meta[d] = c_meta[i]; b.p_umi[d] = c_umi[i]; b.p_frag[d] = c_frag[i]; b.p_dist[d] = c_dist[i];
+                pm[d] = c_meta[i]; pu[d] = c_umi[i]; pf[d] = c_frag[i]; pd[d] = c_dist[i];
             }
-            smc_locus& L = b.p_loci[(size_t)l];
+            for (size_t d = o + n; d < (size_t)off[(size_t)l + 1]; ++d) pm[d] = pu[d] = pf[d] = pd[d] = 0u;   // padding
+            smc_locus& L = ploci[(size_t)l];
             L.read_off4 = (uint32_t)(o / 4);
             L.umi_off = (uint32_t)t_ustart[(size_t)t].size();   // thread-relative; rebased after the join
             L.n_reads = (int32_t)n; L.n_umi = (int32_t)nu; L.n_frag = (int32_t)nf;
@@ -562,7 +676,7 @@ int64_t smc_bam_planes(void* h, const char* chrom, int64_t start0, int64_t end0,
     b.p_umi_start.clear();
     for (int t = 0; t < T; ++t) {
         const uint32_t base = (uint32_t)b.p_umi_start.size();
-        for (int64_t l = cut[(size_t)t]; l < cut[(size_t)t + 1]; ++l) b.p_loci[(size_t)l].umi_off += base;
+        for (int64_t l = cut[(size_t)t]; l < cut[(size_t)t + 1]; ++l) ploci[(size_t)l].umi_off += base;
         b.p_umi_start.insert(b.p_umi_start.end(), t_ustart[(size_t)t].begin(), t_ustart[(size_t)t].end());
         b.keys += t_keys[(size_t)t];
         b.ds_info += t_ds[(size_t)t];
@@ -578,14 +692,10 @@ int64_t smc_bam_planes(void* h, const char* chrom, int64_t start0, int64_t end0,
     return total;
 }
 
-void smc_bam_planes_copy(void* h, uint32_t* meta, uint32_t* umi, uint32_t* frag, uint32_t* dist, uint32_t* umi_start,
-                         void* loci, int32_t* n_keys, char* keys) {
+// the small per-run outputs of the last smc_bam_planes: umi_start, extra allele keys
+void smc_bam_planes_copy(void* h, uint32_t* umi_start, int32_t* n_keys, char* keys) {
     Bam& b = *(Bam*)h;
-    const size_t n = b.p_meta.size();
-    memcpy(meta, b.p_meta.data(), 4 * n); memcpy(umi, b.p_umi.data(), 4 * n);
-    memcpy(frag, b.p_frag.data(), 4 * n); memcpy(dist, b.p_dist.data(), 4 * n);
     memcpy(umi_start, b.p_umi_start.data(), 4 * b.p_umi_start.size());
-    memcpy(loci, b.p_loci.data(), sizeof(smc_locus) * b.p_loci.size());
     memcpy(n_keys, b.n_keys.data(), 4 * b.n_keys.size());
     memcpy(keys, b.keys.data(), b.keys.size());
 }

@@ -19,16 +19,29 @@ import decimal
 _M64 = (1 << 64) - 1
 
 
-def py2_round(x: float, ndigits: int = 0) -> float:
-    """CPython 2.7 `round(x, ndigits)`: correctly rounded, ties away from zero."""
-    if x != x or x in (float("inf"), float("-inf")):
-        return x
+def _py2_round_exact(x: float, ndigits: int) -> float:
     q = decimal.Decimal(1).scaleb(-ndigits)
     d = decimal.Decimal(x).quantize(q, rounding=decimal.ROUND_HALF_UP)
     r = float(d)
     if r == 0.0 and (x < 0 or str(x).startswith("-")):
         return -0.0
     return r
+
+
+def py2_round(x: float, ndigits: int = 0) -> float:
+    """CPython 2.7 `round(x, ndigits)`: correctly rounded, ties away from zero.
+
+    This interpreter's `round` is correctly rounded too and differs only on exact ties (half to even).  A double
+    is a dyadic rational, so x * 10^n can be exactly half-way between integers only when x * 2^(n+1) is an odd
+    integer (x = odd / 2^(n+1)); that scaling is exact in floating point, so the test is: everything else takes
+    the built-in."""
+    if x != x or x in (float("inf"), float("-inf")):
+        return x
+    if 0 <= ndigits <= 20:
+        t = x * (1 << (ndigits + 1))
+        if t != int(t) or not (int(t) & 1):
+            return round(x, ndigits)
+    return _py2_round_exact(x, ndigits)
 
 
 def py2_str_float(x: float) -> str:

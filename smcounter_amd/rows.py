@@ -86,6 +86,51 @@ def format_row(row, chrom: str, pos, orig_ref: str, alleles, params: VcParams, r
     return "\t".join(py2_str(x) for x in out)
 
 
+def _fmt_float(x: float) -> str:
+    # py2 str(float) of an already rounded value ('%.12g' + '.0' for integers), inlined for the batch path
+    s = "%.12g" % x
+    if "." not in s and "e" not in s and "n" not in s:
+        s += ".0"
+    return s
+
+
 def format_rows(rows, db, params: VcParams, refprov):
-    return [format_row(rows[l], db.chrom[l], db.pos[l], db.ref[l], db.alleles[l], params, refprov)
-            for l in range(len(rows))]
+    """`format_row` over a batch.  Loci whose candidate goes through no filter and is not bi-allelic (nearly all
+    of a panel) take a column-wise path - the structured array is unpacked once into Python lists instead of one
+    numpy field access per value; the others go through `format_row`.  Same strings either way
+    (tests/test_host_logic.py compares the two on the golden loci)."""
+    n = len(rows)
+    if n == 0:
+        return []
+    st = rows["status"].tolist()
+    cand0 = rows["cand"][:, 0]
+    simple = ((rows["status"] & 0xff) == 0) & ((rows["status"] & abi.ST_BAD_INPUT) == 0) & (rows["biallelic"] == 0) \
+        & (cand0["flt_applied"] == 0)
+    simple = simple.tolist()
+    cols = {k: rows[k].tolist() for k in ("cvg", "all_frag", "all_mt", "used_frag", "used_mt", "mt3", "mt5", "mt7", "mt10",
+                                          "dp", "umt", "vsm", "pi")}
+    c_allele, c_pi, c_vdp, c_vmt, c_vsm = (cand0[k].tolist() for k in ("allele", "pi", "vdp", "vmt", "vsm"))
+    rnd, ff = py2_round, _fmt_float
+    out = [None] * n
+    for l in range(n):
+        if not simple[l]:
+            out[l] = format_row(rows[l], db.chrom[l], db.pos[l], db.ref[l], db.alleles[l], params, refprov)
+            continue
+        ref, alt, vtype = convert_to_vcf(db.ref[l], db.alleles[l][c_allele[l]])
+        cvg, used = cols["cvg"][l], cols["used_mt"][l]
+        dp, umt, vsm, pi = cols["dp"][l], cols["umt"][l], cols["vsm"][l], cols["pi"][l]
+        vdp, vmt = c_vdp[l], c_vmt[l]
+        f = [db.chrom[l], str(int(db.pos[l])), ref, alt, vtype, str(cvg), str(cols["all_frag"][l]), str(cols["all_mt"][l]),
+             str(cols["used_frag"][l]), str(used), ff(rnd(c_pi[l], 2)), str(vdp), ff(rnd(1.0 * vdp / cvg, 4)), str(vmt),
+             ff(rnd(1.0 * vmt / used, 4)), str(c_vsm[l]),
+             str(dp[0]), str(dp[1]), str(dp[2]), str(dp[3]),
+             ff(rnd(1.0 * dp[0] / cvg, 4)), ff(rnd(1.0 * dp[1] / cvg, 4)), ff(rnd(1.0 * dp[2] / cvg, 4)),
+             ff(rnd(1.0 * dp[3] / cvg, 4)),
+             str(cols["mt3"][l]), str(cols["mt5"][l]), str(cols["mt7"][l]), str(cols["mt10"][l]),
+             str(umt[0]), str(umt[1]), str(umt[2]), str(umt[3]),
+             ff(rnd(1.0 * umt[0] / used, 4)), ff(rnd(1.0 * umt[1] / used, 4)), ff(rnd(1.0 * umt[2] / used, 4)),
+             ff(rnd(1.0 * umt[3] / used, 4)),
+             str(vsm[0]), str(vsm[1]), str(vsm[2]), str(vsm[3]),
+             ff(rnd(pi[0], 2)), ff(rnd(pi[1], 2)), ff(rnd(pi[2], 2)), ff(rnd(pi[3], 2)), ";"]
+        out[l] = "\t".join(f)
+    return out

@@ -241,3 +241,16 @@ def test_downsampled_golden_fixtures_exercise_the_sample():
         assert R2["status"][l] & abi.ST_BAD_INPUT
         n += 1
     assert n == 2
+
+
+def test_batch_row_formatter_equals_the_per_row_one():
+    import oracle_lib
+    n = 0
+    for path in golden_files():
+        pb, db, P, refp, expected = load_golden(path)
+        R = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE)
+        fast = rows.format_rows(R, db, P, refp)
+        slow = [rows.format_row(R[l], db.chrom[l], db.pos[l], db.ref[l], db.alleles[l], P, refp) for l in range(len(R))]
+        assert fast == slow
+        n += len(R)
+    assert n > 600
