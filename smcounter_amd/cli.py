@@ -63,10 +63,35 @@ def call_shard(args, params: VcParams, loci, device: int):
         batches = bamio.iter_pileup_batches(bamio.BamFile(args.bamFile), ref, loci, max_reads=args.batchReads)
     else:
         batches = bamio.iter_device_batches_native(args.bamFile, ref, loci, params, max_reads=args.batchReads)
-    for first, pb in batches:
+    for first, pb in _prefetch(batches):
         output.extend(vc.vc_batch(pb, params, ref, eng=eng))
     eng.close()
     return output
+
+
+def _prefetch(it, depth: int = 2):
+    """Run a batch generator in a helper thread, `depth` batches ahead: the native decoder releases the GIL, so
+    decoding batch i + 1 overlaps the GPU call and the string formatting of batch i."""
+    import queue
+    import threading
+    q = queue.Queue(maxsize=depth)
+    done = object()
+
+    def work():
+        try:
+            for item in it:
+                q.put(item)
+            q.put(done)
+        except BaseException as e:          # re-raised in the consumer
+            q.put(e)
+    threading.Thread(target=work, daemon=True).start()
+    while True:
+        item = q.get()
+        if item is done:
+            return
+        if isinstance(item, BaseException):
+            raise item
+        yield item
 
 
 def main(args) -> int:

@@ -68,11 +68,36 @@ def test_stress_mix_of_sizes_and_bins(engine0):
 
 
 def test_huge_locus_uses_global_tables(engine0):
-    """One locus too large for LDS tables (> 160 KB): the global-scratch bin."""
-    cfg = synth.SynthConfig("big", 2, 3000, 12, 99)
+    """Loci too large for LDS tables (> 160 KB): the global-scratch bin (checked through the plan's scratch size)."""
+    cfg = synth.SynthConfig("big", 2, 7000, 12, 99)
     P = synth.params_for(cfg)
     db = synth.generate_native(cfg, 0, 2, P)
-    assert 8 * int(db.loci["n_frag"][0]) > 160 * 1024
+    assert 4 * int(db.loci["n_frag"][0]) > 160 * 1024
+    plan = engine0.make_plan(db.loci)
+    assert plan.info()[1] > 0                       # bytes of global scratch tables
+    got = engine0.call_batch_host(db, P)
+    want, fragile = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE, return_fragile=True)
+    assert abi.compare_rows(got, want, PI_TOL, P_TOL, fragile) == []
+
+
+@pytest.mark.parametrize("seed", range(40, 52))
+def test_randomised_differential(engine0, seed):
+    """Random stress batches under random parameters (quality / mapping-quality cut-offs, mtDrop, barcode cap with and
+    without barcode texts, deep and shallow mixes): every field of every row against the CPU restatement."""
+    rng = np.random.RandomState(seed)
+    deep = bool(seed % 3 == 0)
+    pb, _ = synth.generate_stress(int(rng.randint(20, 90)) if not deep else 5, seed, deep=deep,
+                                  max_umi=int(rng.choice([4, 20, 60, 150])))
+    P = VcParams(mtDepth=int(rng.choice([3, 40, 5000])), rpb=float(rng.choice([1.5, 3.0, 8.6])), hpLen=8,
+                 mtDrop=int(rng.choice([0, 0, 1, 2])), minBQ=int(rng.choice([2, 20, 30])), minMQ=int(rng.choice([0, 30])),
+                 mismatchThr=float(rng.choice([2.0, 6.0, 100.0])), maxMT=int(rng.choice([0, 0, 7])),
+                 primerDist=int(rng.choice([0, 2, 10])))
+    if seed % 2:
+        import dataclasses
+        names = [["BC%05d_%d" % (u, l) for u in range(int(pb.umi[pb.locus_slice(l)].max()) + 1 if pb.read_off[l + 1] > pb.read_off[l] else 0)]
+                 for l in range(pb.n_loci)]
+        pb = dataclasses.replace(pb, umi_names=names)     # host-side py2 down-sampling where over the cap
+    db = features.extract_features(pb, P)
     got = engine0.call_batch_host(db, P)
     want, fragile = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE, return_fragile=True)
     assert abi.compare_rows(got, want, PI_TOL, P_TOL, fragile) == []
