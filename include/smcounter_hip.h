@@ -62,6 +62,31 @@ extern "C" {
 #define SMC_KIND_INS 2
 #define SMC_KIND_DELSTART 3
 
+/* Read class: bits 27-31 of every `frag` plane word (bits 0-26 hold the fragment slot). What a read adds to its
+ * allele's tallies and whether it enters bcDict depends only on a handful of predicates that the feature extraction
+ * knows (it has the run's parameters): the class names the combination, the default kernel looks the tally
+ * increments up by class and never touches base quality / MAPQ / distance arithmetic for the tallies, nor the
+ * `dist` plane at all. incCond = (bq >= minBQ or in-deletion) and mapq >= minMQ and mismatch-ok (smCounter.py:378).
+ *   in-deletion ('DEL', kind 1):                  0 + incCond
+ *   insertion / deletion start (kind 2, 3):       2 + 2 * reverse + incCond
+ *   regular base (kind 0):                        6 + 8 * reverse + sub, with sub =
+ *       0 not included, bq >= minBQ   1 not included, bq < minBQ (lowQReads, :428)
+ *       2 included read 1, distToBcEnd > 20   3 included read 1, distToBcEnd <= 20            (:432-440)
+ *       4 + (distToBcEnd <= 20) + 2 * (distToPrimerEnd <= primerDist)   included read 2       (:441-452)
+ * The raw fields stay in the planes (the CPU restatement and the sorted-stream kernel compute from them). */
+#define SMC_FRAG_SLOT_MASK 0x07FFFFFFu
+#define SMC_FRAG_CLASS_SHIFT 27
+#define SMC_N_READ_CLASS 22
+static inline uint32_t smc_read_class(int kind, int rev, int r2, int inc, int bq_ok, int le20, int prle) {
+    if (kind == 1) return (uint32_t)(0 + (inc ? 1 : 0));
+    if (kind != 0) return (uint32_t)(2 + (rev ? 2 : 0) + (inc ? 1 : 0));
+    uint32_t sub;
+    if (!inc) sub = bq_ok ? 0u : 1u;
+    else if (!r2) sub = 2u + (le20 ? 1u : 0u);
+    else sub = 4u + (le20 ? 1u : 0u) + (prle ? 2u : 0u);
+    return 6u + (rev ? 8u : 0u) + sub;
+}
+
 /* The numeric arguments vc() receives (smCounter.py:274) that the device path needs, plus the two
  * values vc() derives before the pileup loop. mismatchThr and hpLen are consumed on the host
  * (feature extraction / reference-sequence test). */

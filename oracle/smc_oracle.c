@@ -170,7 +170,7 @@ static int call_locus(const smc_params* P, const smc_locus* L, const uint32_t* m
      * locus-level slot; a barcode's fragments are the slots between its smallest and largest. */
     for (int u = 0; u < nU; ++u) { foff[u] = L->n_frag; nfrag[u] = 0; }
     for (int i = 0; i < n; ++i) {
-        uint32_t u = umi[i], f = frag[i];
+        uint32_t u = umi[i], f = frag[i] & SMC_FRAG_SLOT_MASK;   /* (bits 27-31: the read class, not used here) */
         if (u >= (uint32_t)nU || f >= (uint32_t)L->n_frag || (meta[i] & 0xff) >= L->n_alleles) { bad = 1; continue; }
         if ((int)f < foff[u]) foff[u] = (int)f;
         if ((int)f + 1 > nfrag[u]) nfrag[u] = (int)f + 1;      /* end of the range, for now */
@@ -210,7 +210,7 @@ static int call_locus(const smc_params* P, const smc_locus* L, const uint32_t* m
         if (inc) {                                                       /* :467-479 */
             uint32_t u = umi[i];
             if (!in_bc[u]) { in_bc[u] = 1; bc_order[n_bc++] = (int)u; }
-            frag_t* s = &ft[frag[i]];
+            frag_t* s = &ft[frag[i] & SMC_FRAG_SLOT_MASK];
             double prob = pow(10.0, -bq / 10.0);
             if (!s->present) {
                 s->present = 1; s->paired = 0; s->base = (unsigned char)a; s->prob = prob; s->seq = stamp++;

@@ -238,7 +238,7 @@ def call_batch(db, params, n_cpu=1, loci=None, pool=None):
         if int(L["flags"]) & 1:
             us = db.umi_start[int(L["umi_off"]):int(L["umi_off"]) + int(L["n_umi"])]
             dropped = set(np.nonzero(us >> 31)[0].tolist())
-        tasks.append((db.meta[o:o + n], db.umi[o:o + n], db.frag[o:o + n], db.dist[o:o + n], int(L["ref_allele"]),
+        tasks.append((db.meta[o:o + n], db.umi[o:o + n], db.frag[o:o + n] & 0x07FFFFFF, db.dist[o:o + n], int(L["ref_allele"]),
                       int(L["n_alleles"]), int(L["snp_mask"]), params.minBQ, params.minMQ, params.mtDrop,
                       params.primerDist, params.ds, params.smt, dropped))
     if n_cpu <= 1 and pool is None:

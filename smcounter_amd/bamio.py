@@ -511,7 +511,7 @@ def _native_lib():
         lib.smc_bam_keys_len.restype = C.c_int64
         lib.smc_bam_copy.argtypes = [C.c_void_p] * 18
         lib.smc_bam_planes.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int64, C.c_double,
-                                       C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, _PLANES_ALLOC, C.c_void_p] \
+                                       C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _PLANES_ALLOC, C.c_void_p] \
             + [C.POINTER(C.c_int64)] * 3
         lib.smc_bam_ds_info.argtypes = [C.c_void_p]
         lib.smc_bam_ds_info.restype = C.c_char_p
@@ -599,7 +599,8 @@ class NativeBam(object):
             out[4] = got["loci"].ctypes.data
         cb = _PLANES_ALLOC(alloc)
         n = self._lib.smc_bam_planes(self._h, chrom.encode(), lo, hi, max_reads, float(params.mismatchThr), refb,
-                                     int(nthreads), int(params.ds), int(params.minBQ), int(params.minMQ), cb, None,
+                                     int(nthreads), int(params.ds), int(params.minBQ), int(params.minMQ),
+                                     int(params.primerDist), cb, None,
                                      C.byref(done), C.byref(n_slots), C.byref(n_us))
         if n < 0:
             msg = self._lib.smc_bam_error(self._h).decode()

@@ -519,8 +519,9 @@ void smc_bam_copy(void* h, uint32_t* umi, uint32_t* frag, uint8_t* flag, uint8_t
 // with an smc_locus[n_loci] buffer (uninitialised memory is fine: every entry, padding included, is written).
 typedef void (*smc_planes_alloc)(void* ctx, int64_t n_slots, int64_t n_loci, void** out);
 int64_t smc_bam_planes(void* h, const char* chrom, int64_t start0, int64_t end0, int64_t max_reads, double mismatch_thr,
-                       const char* refseq, int nthreads, int ds, int min_bq, int min_mq, smc_planes_alloc alloc,
-                       void* alloc_ctx, int64_t* n_loci_done, int64_t* n_slots, int64_t* n_umi_start) {
+                       const char* refseq, int nthreads, int ds, int min_bq, int min_mq, int primer_dist,
+                       smc_planes_alloc alloc, void* alloc_ctx, int64_t* n_loci_done, int64_t* n_slots,
+                       int64_t* n_umi_start) {
     Bam& b = *(Bam*)h;
     b.keys.clear(); b.n_keys.clear(); b.ds_info.clear();
     b.io_threads = nthreads;
@@ -575,6 +576,7 @@ int64_t smc_bam_planes(void* h, const char* chrom, int64_t start0, int64_t end0,
         std::vector<int64_t> bc_stamp((size_t)n_bc, -1), pair_stamp((size_t)n_pair, -1);
         std::vector<int32_t> bc_local((size_t)n_bc), pair_local((size_t)n_pair), n_frag_of, n_reads_of, slot_base, slot_cnt;
         std::vector<uint32_t> c_meta, c_umi, c_frag, c_dist;
+        std::vector<uint8_t> c_class;
         std::vector<int32_t> gid_of_u, inc_order;
         std::vector<uint8_t> inc_seen;
         std::vector<std::string> extra;
@@ -583,7 +585,7 @@ int64_t smc_bam_planes(void* h, const char* chrom, int64_t start0, int64_t end0,
             const int64_t p0 = start0 + l;
             while (w0 < reads.size() && reads[w0].end <= p0) ++w0;
             extra.clear(); n_frag_of.clear(); n_reads_of.clear(); gid_of_u.clear(); inc_order.clear(); inc_seen.clear();
-            c_meta.clear(); c_umi.clear(); c_frag.clear(); c_dist.clear();
+            c_meta.clear(); c_umi.clear(); c_frag.clear(); c_dist.clear(); c_class.clear();
             bool r2 = false, first = true;
             for (size_t ri = w0; ri < reads.size(); ++ri) {
                 const Aln& a = reads[ri];
@@ -619,9 +621,11 @@ int64_t smc_bam_planes(void* h, const char* chrom, int64_t start0, int64_t end0,
                     const int64_t dbc = r2 ? (rev ? rel : far) : (rev ? far : rel), dpr = r2 ? (rev ? far : rel) : 0;
                     dist = (uint32_t)std::min<int64_t>(65535, std::max<int64_t>(0, dbc)) | (uint32_t)std::min<int64_t>(65535, std::max<int64_t>(0, dpr)) << 16;
                 }
-                if (ds > 0 && !inc_seen[(size_t)u] && ((int)bq >= min_bq || kind == 1) && (int)a.mapq >= min_mq && (flags & 4u)) {
-                    inc_seen[(size_t)u] = 1; inc_order.push_back(u);
-                }
+                const bool bq_ok = (int)bq >= min_bq;
+                const bool inc = (bq_ok || kind == 1) && (int)a.mapq >= min_mq && (flags & 4u);     // incCond, :378
+                if (ds > 0 && !inc_seen[(size_t)u] && inc) { inc_seen[(size_t)u] = 1; inc_order.push_back(u); }
+                c_class.push_back((uint8_t)smc_read_class((int)kind, rev, r2, inc, bq_ok, (dist & 0xffffu) <= 20u,
+                                                         (int)(dist >> 16) <= primer_dist));
                 c_meta.push_back((uint32_t)ai | bq << 8 | flags << 16 | (uint32_t)a.mapq << 24);
                 c_umi.push_back((uint32_t)u); c_frag.push_back((uint32_t)f); c_dist.push_back(dist);
             }
@@ -636,7 +640,7 @@ int64_t smc_bam_planes(void* h, const char* chrom, int64_t start0, int64_t end0,
             const size_t o = (size_t)off[(size_t)l];
             for (size_t i = 0; i < n; ++i) {
                 const size_t d = o + (size_t)slot_cnt[c_frag[i]]++;
-                pm[d] = c_meta[i]; pu[d] = c_umi[i]; pf[d] = c_frag[i]; pd[d] = c_dist[i];
+                pm[d] = c_meta[i]; pu[d] = c_umi[i]; pf[d] = c_frag[i] | (uint32_t)c_class[i] << SMC_FRAG_CLASS_SHIFT; pd[d] = c_dist[i];
             }
             for (size_t d = o + n; d < (size_t)off[(size_t)l + 1]; ++d) pm[d] = pu[d] = pf[d] = pd[d] = 0u;   // padding
             smc_locus& L = ploci[(size_t)l];

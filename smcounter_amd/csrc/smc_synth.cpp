@@ -61,6 +61,7 @@ typedef struct smc_synth_cfg {
     int64_t start_pos;
     double p_overlap, p_err, p_gap, p_ins, p_delstart, p_n, alt_locus_frac, alt_af;
     double mismatch_thr;
+    int32_t min_bq, min_mq, primer_dist, pad_;   // the run's parameters: the read class (frag bits 27-31) depends on them
 } smc_synth_cfg;
 
 // slots needed for loci [lo,hi): every locus padded to a multiple of 4 reads
@@ -197,7 +198,12 @@ int smc_synth_generate(const smc_synth_cfg* c, int64_t lo, int64_t hi, uint32_t*
                 if (al == 254) al = ins_id; else if (al == 253) al = dst_id;
                 meta[off + i] = (uint32_t)al | ((uint32_t)r.bq << 8) | ((uint32_t)r.flags << 16) | ((uint32_t)r.mq << 24);
                 umi[off + i] = r.umi;
-                frag[off + i] = r.frag;
+                {
+                    const int kind = (r.flags >> SMC_KIND_SHIFT) & 3, bq_ok = r.bq >= c->min_bq;
+                    const int inc = (bq_ok || kind == SMC_KIND_GAP) && r.mq >= c->min_mq && (r.flags & SMC_FL_MMOK);
+                    frag[off + i] = r.frag | smc_read_class(kind, r.flags & SMC_FL_REV, r.flags & SMC_FL_R2, inc, bq_ok, r.dbc <= 20,
+                                                            r.dpr <= c->primer_dist) << SMC_FRAG_CLASS_SHIFT;
+                }
                 dist[off + i] = (uint32_t)r.dbc | ((uint32_t)r.dpr << 16);
             }
             for (int64_t i = R; i < stride; ++i) meta[off + i] = umi[off + i] = frag[off + i] = dist[off + i] = 0;

@@ -96,7 +96,7 @@ __device__ unsigned long long g_stamps[16];
 __device__ __forceinline__ uint32_t lds_hdr_bytes(int a_cap) {
     // Hdr + tal[a_cap][SMC_NT] + pifx[a_cap] (u64) + mtc[a_cap] + strong[a_cap] + lut[LUT_N] doubles
     // (the row is staged over the LUT, which is dead by then)
-    return (uint32_t)(sizeof(Hdr) + a_cap * SMC_NT * 4 + a_cap * 8 + a_cap * 4 + a_cap * 4 + 128 * 8);
+    return (uint32_t)(sizeof(Hdr) + a_cap * SMC_NT * 4 + a_cap * 8 + a_cap * 4 + a_cap * 4 + 128 * 8 + 32 * 8);
 }
 
 __device__ __forceinline__ double wave_reduce_mul(double v, int width) {
@@ -161,6 +161,10 @@ __device__ __forceinline__ long long wave_add64(long long v) {
 // The index is the merged quality of a 'Paired' fragment (error prob 10^(-q/10)) or PIDX_UNPAIRED
 // for a single read (prob forced to 0.1, smCounter.py:67-68); qualities are <= 126 by the batch contract
 // (a BAM holds 0..93) and clamped to that.
+// read-class table entry (two words): nine 5-bit tally increments in SMC_T_* order (six in .x, three in .y),
+// .y bit 30 = the read enters bcDict (incCond), .y bit 31 = the read is inside a deletion
+#define CLS_INC 0x40000000u
+#define CLS_GAP 0x80000000u
 #define ST_PRESENT 0x80000000u
 #define ST_PAIRED 0x40000000u
 // raw fragment word (P1): first read in bits 0-13 (allele << 8 | quality), second in 14-27
@@ -358,7 +362,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
     const int n = L.n_reads, nU = L.n_umi, nF = L.n_frag, nA = L.n_alleles;
     const uint4* meta4 = (const uint4*)(g_meta + 4ll * L.read_off4);
     const uint4* frag4 = (const uint4*)(g_frag + 4ll * L.read_off4);
-    const uint4* dist4 = (const uint4*)(g_dist + 4ll * L.read_off4);
 
     // ---- carve LDS
     Hdr* H = (Hdr*)smem;
@@ -368,6 +371,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
     uint32_t* strong = mtc + a_cap;
     double* lut = (double*)(strong + a_cap);                         // [LUT_N]
     smc_row* rowst = (smc_row*)lut;                                   // row stage: over the LUT once it is dead
+    uint2* cls_lut = (uint2*)(lut + LUT_N);                           // [32] read class -> tally increments / flags
     static_assert(sizeof(smc_row) <= LUT_N * sizeof(double), "row stage must fit in the LUT");
     unsigned char* tab = GLOBAL_TABLES ? (scratch + scratch_off[blockIdx.x]) : (smem + lds_hdr_bytes(a_cap));
     uint32_t* umi_base = (uint32_t*)tab;                              // [nU+1] first slot of each barcode
@@ -381,16 +385,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
     STAMP_INIT();
     // first step's reads are requested before the LDS image is initialised (HBM latency overlaps it)
     const int n4 = (n + 3) >> 2;
-    uint4 m4, f4, d4;
-    // + the two reads before the lane's quad (slot of both, meta of the last): a read's rank inside its fragment
+    uint4 m4, f4;
+    // + the frag words of the two reads before the lane's quad: a read's rank inside its fragment
     // comes from its predecessors, which sit right before it in barcode-major order
     uint2 pf2 = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-    uint32_t pm1 = 0;
     const uint2* frag2 = (const uint2*)frag4;
     if (tid < n4) {
-        m4 = meta4[tid]; f4 = frag4[tid]; d4 = dist4[tid];
+        m4 = meta4[tid]; f4 = frag4[tid];
         // (only the first lane of a wavefront fetches them; the others take them from their neighbour lane)
-        if (lane == 0 && tid > 0) { pf2 = frag2[2 * tid - 1]; pm1 = ((const uint32_t*)meta4)[4 * tid - 1]; }
+        if (lane == 0 && tid > 0) pf2 = frag2[2 * tid - 1];
     }
     // ---- S0: init
     uint32_t b0_early = 0xFFFFFFFFu;
@@ -401,6 +404,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         for (int i = tid; i < nF; i += BLOCK) fmin[i] = 0u;
         // quality -> error-probability table (read by the calProb phase; 'unpaired' -> 0.1, smCounter.py:65-68)
         for (int i = tid; i < LUT_N; i += BLOCK) lut[i] = i == (int)PIDX_UNPAIRED ? 0.1 : g_lut[i];
+        if (tid < 32) cls_lut[tid] = ((const uint2*)(g_lut + 256))[tid];   // the class table sits behind the quality table
         // first read of every barcode (+ closing entry); S2 turns it into the first fragment slot
         const uint32_t* ustart = g_umi_start + L.umi_off;
         for (int i = tid; i <= nU; i += BLOCK) umi_base[i] = ustart[i] & ~SMC_USTART_DROPPED;
@@ -411,7 +415,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         // HBM once (a gather after the scan finds them evicted: + 10 % traffic)
         if (nU <= BLOCK && tid < nU) {
             const uint32_t r0 = ustart[tid] & ~SMC_USTART_DROPPED;
-            b0_early = r0 < (uint32_t)n ? (g_frag + 4ll * L.read_off4)[r0] : 0xFFFFFFFFu;
+            b0_early = r0 < (uint32_t)n ? ((g_frag + 4ll * L.read_off4)[r0] & SMC_FRAG_SLOT_MASK) : 0xFFFFFFFFu;
         }
     }
     __syncthreads();
@@ -427,95 +431,94 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         uint32_t accv[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) accv[k] = 0;
+        // per-lane tallies of the reference allele, nine 5-bit fields in two words (the class table's layout);
+        // a step adds at most 4 to a field, so they are spilled into accv[] every 7 steps
+        uint32_t acc0 = 0, acc1 = 0;
+        int steps = 0;
+        auto spill = [&]() {
+#pragma unroll
+            for (int t = 0; t < 6; ++t) accv[t] += (acc0 >> (5 * t)) & 31u;
+#pragma unroll
+            for (int t = 6; t < 9; ++t) accv[t] += (acc1 >> (5 * (t - 6))) & 31u;
+            acc0 = acc1 = 0u;
+        };
         uint32_t n_inc_s = 0;
         lmask err_m = 0, ovf_any = 0;
         const uint32_t refa = L.ref_allele;
         for (int qb = 0; qb < n4; qb += BLOCK) {
             const int q = qb + tid;
-            const uint4 cm = m4, cf = f4, cd = d4;
+            const uint4 cm = m4, cf = f4;
             const uint2 cpf = pf2;
-            const uint32_t cpm = pm1;
             {   // prefetch the next step while this one is processed
                 const int qn = q + BLOCK;
                 if (qn < n4) {
-                    m4 = meta4[qn]; f4 = frag4[qn]; d4 = dist4[qn];
-                    if (lane == 0) { pf2 = frag2[2 * qn - 1]; pm1 = ((const uint32_t*)meta4)[4 * qn - 1]; }
+                    m4 = meta4[qn]; f4 = frag4[qn];
+                    if (lane == 0) pf2 = frag2[2 * qn - 1];
                 }
             }
             const uint32_t ms[4] = {cm.x, cm.y, cm.z, cm.w};
-            const uint32_t fs[4] = {cf.x, cf.y, cf.z, cf.w}, ds[4] = {cd.x, cd.y, cd.z, cd.w};
+            const uint32_t fw[4] = {cf.x, cf.y, cf.z, cf.w};
+            // What each read adds: looked up by its class (frag word bits 27-31; smcounter_hip.h) - four LDS reads
+            // issued together; + the class of the read just before the quad (lane 0's loaded word; the other lanes
+            // read a dummy entry)
+            uint2 cw[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cw[k] = cls_lut[fw[k] >> SMC_FRAG_CLASS_SHIFT];
+            const uint2 cwp = cls_lut[cpf.y >> SMC_FRAG_CLASS_SHIFT];
+            const uint32_t fs[4] = {fw[0] & SMC_FRAG_SLOT_MASK, fw[1] & SMC_FRAG_SLOT_MASK, fw[2] & SMC_FRAG_SLOT_MASK,
+                                    fw[3] & SMC_FRAG_SLOT_MASK};
             // slots of the two reads before the quad: the neighbour lane's last two (wavefront shift right by one
-            // lane, DPP), lane 0 keeps what it loaded; inclusion of the read just before the quad likewise
-            // (same test as below - the neighbour's fourth read, or lane 0's loaded word)
-            const uint32_t fprev1 = (uint32_t)__builtin_amdgcn_update_dpp((int)cpf.y, (int)fs[3], 0x138, 0xF, 0xF, false);
-            const uint32_t fprev2 = (uint32_t)__builtin_amdgcn_update_dpp((int)cpf.x, (int)fs[2], 0x138, 0xF, 0xF, false);
-            lmask m_inc_prev;
-            {
-                auto inc_of = [&](uint32_t w) {
-                    return (BAL((int)((w >> 8) & 0xffu) >= P.min_bq) | BAL(((w >> 19) & 3u) == SMC_KIND_GAP)) &
-                           BAL((int)(w >> 24) >= P.min_mq) & BAL((w & 0x40000u) != 0u);
-                };
-                const lmask m_ok3 = BAL(4 * q + 3 < n) & BAL(fs[3] < (uint32_t)nF) & BAL((ms[3] & 0xffu) < (uint32_t)nA);
-                m_inc_prev = ((inc_of(ms[3]) & m_ok3) << 1) | (inc_of(cpm) & BAL(q > 0) & 1ull);
-            }
+            // lane, DPP), lane 0 keeps what it loaded
+            const uint32_t fprev1 = (uint32_t)__builtin_amdgcn_update_dpp((int)(cpf.y & SMC_FRAG_SLOT_MASK), (int)fs[3], 0x138, 0xF, 0xF, false);
+            const uint32_t fprev2 = (uint32_t)__builtin_amdgcn_update_dpp((int)(cpf.x & SMC_FRAG_SLOT_MASK), (int)fs[2], 0x138, 0xF, 0xF, false);
+            lmask m_okk[4], m_inck[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int i = 4 * q + k;
-                const uint32_t mw = ms[k], f = fs[k], dw = ds[k];
-                const uint32_t a = mw & 0xffu, kind = (mw >> 19) & 3u;
-                const lmask m_valid = BAL(i < n);                         // n4 = ceil(n/4): q < n4 follows
-                const lmask m_ok = m_valid & BAL(f < (uint32_t)nF) & BAL(a < (uint32_t)nA);
-                err_m |= m_valid & ~m_ok;
-                const lmask m_base = BAL(kind == SMC_KIND_BASE), m_gap = BAL(kind == SMC_KIND_GAP);
-                const lmask m_qok = BAL((int)((mw >> 8) & 0xffu) >= P.min_bq);            // :378 first term / :428
-                const lmask m_inc = m_ok & (m_qok | m_gap) & BAL((int)(mw >> 24) >= P.min_mq) & BAL((mw & 0x40000u) != 0u);
-                const lmask m_r2 = BAL((mw & 0x10000u) != 0u), m_rev = BAL((mw & 0x20000u) != 0u);
+                const lmask m_valid = BAL(4 * q + k < n);                 // n4 = ceil(n/4): q < n4 follows
+                m_okk[k] = m_valid & BAL(fs[k] < (uint32_t)nF) & BAL((ms[k] & 0xffu) < (uint32_t)nA) &
+                           BAL((fw[k] >> SMC_FRAG_CLASS_SHIFT) < (uint32_t)SMC_N_READ_CLASS);
+                err_m |= m_valid & ~m_okk[k];
+                m_inck[k] = m_okk[k] & BAL((cw[k].y & CLS_INC) != 0u);    // incCond (:378), evaluated by the host
+            }
+            // inclusion of the read just before the quad: the neighbour lane's fourth read, or lane 0's loaded one
+            lmask m_inc_prev = (m_inck[3] << 1) | (BAL((cwp.y & CLS_INC) != 0u) & BAL(q > 0) & 1ull);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t mw = ms[k], f = fs[k];
+                const uint32_t a = mw & 0xffu;
+                const lmask m_ok = m_okk[k], m_inc = m_inck[k];
                 const lmask m_ref = m_ok & BAL(a == refa);
-                const lmask m_ib = m_inc & m_base;
-                const lmask m_r1i = m_ib & ~m_r2, m_r2i = m_ib & m_r2;
-                const lmask m_le20 = BAL((dw & 0xffffu) <= 20u), m_prle = BAL((int)(dw >> 16) <= P.primer_dist);
-                const lmask e_fwd = ~m_gap & ~m_rev, e_rev = ~m_gap & m_rev, e_lowq = m_base & ~m_qok;
+                const lmask m_gap = BAL((int)cw[k].y < 0);
                 n_inc_s += (uint32_t)__popcll(m_inc);
-                ADDM(accv[SMC_T_CNT], m_ref);
-                ADDM(accv[SMC_T_FWD], m_ref & e_fwd);
-                ADDM(accv[SMC_T_REV], m_ref & e_rev);
-                ADDM(accv[SMC_T_LOWQ], m_ref & e_lowq);
-                ADDM(accv[SMC_T_R1N], m_ref & m_r1i);
-                ADDM(accv[SMC_T_R1LE], m_ref & m_r1i & m_le20);
-                ADDM(accv[SMC_T_R2N], m_ref & m_r2i);
-                ADDM(accv[SMC_T_R2BCLE], m_ref & m_r2i & m_le20);
-                ADDM(accv[SMC_T_R2PRLE], m_ref & m_r2i & m_prle);
+                acc0 += LANES(m_ref) ? cw[k].x : 0u;
+                acc1 += LANES(m_ref) ? (cw[k].y & 0x7FFFu) : 0u;
                 lmask nr = m_ok & ~m_ref;
-                if (nr && __popcll(nr) <= 6) {
-                    // a few stray reads (sequencing errors): one predicated LDS add per tally, no loop
-                    uint32_t* t = tal + a * SMC_NT;
-                    if (LANES(nr)) atomicAdd(&t[SMC_T_CNT], 1u);
-                    if (LANES(nr & e_fwd)) atomicAdd(&t[SMC_T_FWD], 1u);
-                    if (LANES(nr & e_rev)) atomicAdd(&t[SMC_T_REV], 1u);
-                    if (LANES(nr & e_lowq)) atomicAdd(&t[SMC_T_LOWQ], 1u);
-                    if (LANES(nr & m_r1i)) atomicAdd(&t[SMC_T_R1N], 1u);
-                    if (LANES(nr & m_r1i & m_le20)) atomicAdd(&t[SMC_T_R1LE], 1u);
-                    if (LANES(nr & m_r2i)) atomicAdd(&t[SMC_T_R2N], 1u);
-                    if (LANES(nr & m_r2i & m_le20)) atomicAdd(&t[SMC_T_R2BCLE], 1u);
-                    if (LANES(nr & m_r2i & m_prle)) atomicAdd(&t[SMC_T_R2PRLE], 1u);
-                } else if (nr) {                                        // many: aggregate per allele
-                    while (nr) {
-                        const int src = __ffsll((long long)nr) - 1;
-                        const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)a, src);
-                        const lmask ma = m_ok & BAL(a == a0);
-                        nr &= ~ma;
-                        if (lane == 0) {
-                            uint32_t* t = tal + a0 * SMC_NT;
-                            uint32_t c;
-                            atomicAdd(&t[SMC_T_CNT], (uint32_t)__popcll(ma));
-                            if ((c = __popcll(ma & e_fwd))) atomicAdd(&t[SMC_T_FWD], c);
-                            if ((c = __popcll(ma & e_rev))) atomicAdd(&t[SMC_T_REV], c);
-                            if ((c = __popcll(ma & e_lowq))) atomicAdd(&t[SMC_T_LOWQ], c);
-                            if ((c = __popcll(ma & m_r1i))) atomicAdd(&t[SMC_T_R1N], c);
-                            if ((c = __popcll(ma & m_r1i & m_le20))) atomicAdd(&t[SMC_T_R1LE], c);
-                            if ((c = __popcll(ma & m_r2i))) atomicAdd(&t[SMC_T_R2N], c);
-                            if ((c = __popcll(ma & m_r2i & m_le20))) atomicAdd(&t[SMC_T_R2BCLE], c);
-                            if ((c = __popcll(ma & m_r2i & m_prle))) atomicAdd(&t[SMC_T_R2PRLE], c);
+                if (nr) {
+                    // stray reads (sequencing errors, indel alleles): the class's increments, one tally at a time
+                    lmask tm[9];
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) tm[t] = BAL(((cw[k].x >> (5 * t)) & 1u) != 0u);
+#pragma unroll
+                    for (int t = 6; t < 9; ++t) tm[t] = BAL(((cw[k].y >> (5 * (t - 6))) & 1u) != 0u);
+                    if (__popcll(nr) <= 6) {
+                        uint32_t* t_ = tal + a * SMC_NT;
+#pragma unroll
+                        for (int t = 0; t < 9; ++t)
+                            if (LANES(nr & tm[t])) atomicAdd(&t_[t], 1u);
+                    } else {                                            // many: aggregate per allele
+                        while (nr) {
+                            const int src = __ffsll((long long)nr) - 1;
+                            const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)a, src);
+                            const lmask ma = m_ok & BAL(a == a0);
+                            nr &= ~ma;
+                            if (lane == 0) {
+                                uint32_t* t_ = tal + a0 * SMC_NT;
+#pragma unroll
+                                for (int t = 0; t < 9; ++t) {
+                                    const uint32_t c = (uint32_t)__popcll(ma & tm[t]);
+                                    if (c) atomicAdd(&t_[t], c);
+                                }
+                            }
                         }
                     }
                 }
@@ -542,7 +545,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                     m_inc_prev = m_inc;
                 }
             }
+            if (++steps == 7) { spill(); steps = 0; }
         }
+        spill();
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             const uint32_t v = (uint32_t)wave_add((int)accv[k]);
@@ -567,7 +572,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
             if (u < nU) {
                 const uint32_t r0 = umi_base[u], r1 = umi_base[u + 1];
                 bad |= !(r0 < r1 && r1 <= (uint32_t)n) || (u == 0 && r0 != 0) || (u == nU - 1 && r1 != (uint32_t)n);
-                b0 = nU <= BLOCK ? b0_early : (r0 < (uint32_t)n ? frag[r0] : 0xFFFFFFFFu);
+                b0 = nU <= BLOCK ? b0_early : (r0 < (uint32_t)n ? (frag[r0] & SMC_FRAG_SLOT_MASK) : 0xFFFFFFFFu);
             }
             __syncthreads();                                            // every r1 of this step is read
             if (u < nU) umi_base[u] = b0;
@@ -681,7 +686,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                 r.allele = 0; r.bq_eff = 0;
                 if (i < n) {
                     r = decode_read(meta[i], 0, P);
-                    hit = r.inc && frag[i] == (uint32_t)sb;
+                    hit = r.inc && (frag[i] & SMC_FRAG_SLOT_MASK) == (uint32_t)sb;
                 }
                 unsigned long long hm = __ballot(hit);
                 while (hm) {
@@ -1178,6 +1183,10 @@ struct URec {
 };
 #define UB 64
 #define PK_NONE 0xFFFFFFFFu
+// frag plane words without their read-class bits (this kernel computes the predicates from the raw fields)
+__device__ __forceinline__ uint4 slots_of(uint4 f) {
+    return make_uint4(f.x & SMC_FRAG_SLOT_MASK, f.y & SMC_FRAG_SLOT_MASK, f.z & SMC_FRAG_SLOT_MASK, f.w & SMC_FRAG_SLOT_MASK);
+}
 
 __device__ __forceinline__ uint32_t lds_sorted_bytes(int a_cap) {
     return (uint32_t)(sizeof(Hdr) + a_cap * 64 + sizeof(smc_row) + 128 * 8 + UB * sizeof(URec) + UB * 4);
@@ -1252,7 +1261,7 @@ __global__ __launch_bounds__(WAVE) void k_call_sorted(
         uint4 cm = zero4, cf = none4, cd = zero4, cu = zero4, nm, nf4, nd, nu;
         {
             const uint32_t q = q0 + j;
-            if (q < q1) { cm = meta4[q]; cf = frag4[q]; cd = dist4[q]; cu = umi4[q]; }
+            if (q < q1) { cm = meta4[q]; cf = slots_of(frag4[q]); cd = dist4[q]; cu = umi4[q]; }
         }
         uint32_t carry = PK_NONE;
         bool any_inc = false;
@@ -1261,7 +1270,7 @@ __global__ __launch_bounds__(WAVE) void k_call_sorted(
             {
                 const uint32_t qn = q + G;
                 nm = zero4; nf4 = none4; nd = zero4; nu = zero4;
-                if (qn < q1) { nm = meta4[qn]; nf4 = frag4[qn]; nd = dist4[qn]; nu = umi4[qn]; }
+                if (qn < q1) { nm = meta4[qn]; nf4 = slots_of(frag4[qn]); nd = dist4[qn]; nu = umi4[qn]; }
             }
             const uint32_t ms[4] = {cm.x, cm.y, cm.z, cm.w}, fs[4] = {cf.x, cf.y, cf.z, cf.w};
             const uint32_t ds[4] = {cd.x, cd.y, cd.z, cd.w}, us[4] = {cu.x, cu.y, cu.z, cu.w};
@@ -1737,7 +1746,7 @@ struct smc_ctx {
 };
 
 static size_t host_hdr_bytes(int a_cap) {
-    return sizeof(Hdr) + (size_t)a_cap * SMC_NT * 4 + (size_t)a_cap * 8 + (size_t)a_cap * 4 + (size_t)a_cap * 4 + 128 * 8;
+    return sizeof(Hdr) + (size_t)a_cap * SMC_NT * 4 + (size_t)a_cap * 8 + (size_t)a_cap * 4 + (size_t)a_cap * 4 + 128 * 8 + 32 * 8;
 }
 static size_t table_bytes(const smc_locus& L) {
     size_t b = 4 * ((size_t)L.n_umi + 1) + 4 * (size_t)L.n_frag + 9 * (size_t)L.n_umi;
@@ -1822,8 +1831,34 @@ int smc_create(int device, smc_ctx** out) {
     smc_ctx* c = new smc_ctx();
     c->device = device;
     c->max_lds = 160 * 1024;
-    double h[256];
+    double h[256 + 32];
     for (int q = 0; q < 256; ++q) h[q] = pow(10.0, -q / 10.0);   // smCounter.py:469
+    {
+        // read class -> what the read adds to its allele's tallies (include/smcounter_hip.h: smc_read_class)
+        uint32_t cls[32][2];
+        memset(cls, 0, sizeof cls);
+        for (int kind = 0; kind < 4; ++kind)
+            for (int bits = 0; bits < 64; ++bits) {
+                const int rev = bits & 1, r2 = (bits >> 1) & 1, inc = (bits >> 2) & 1, bq_ok = (bits >> 3) & 1,
+                          le20 = (bits >> 4) & 1, prle = (bits >> 5) & 1;
+                if (kind == SMC_KIND_BASE && inc && !bq_ok) continue;           // included implies bq >= minBQ
+                const uint32_t c_ = smc_read_class(kind, rev, r2, inc, bq_ok, le20, prle);
+                uint32_t f[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                f[SMC_T_CNT] = 1;                                                // :379,401,459
+                if (kind != SMC_KIND_GAP) f[rev ? SMC_T_REV : SMC_T_FWD] = 1;    // :386-389,408-411,454-457
+                if (kind == SMC_KIND_BASE) {
+                    if (!bq_ok) f[SMC_T_LOWQ] = 1;                               // :428-429
+                    if (inc && !r2) { f[SMC_T_R1N] = 1; f[SMC_T_R1LE] = (uint32_t)le20; }                  // :432-440
+                    if (inc && r2) { f[SMC_T_R2N] = 1; f[SMC_T_R2BCLE] = (uint32_t)le20; f[SMC_T_R2PRLE] = (uint32_t)prle; }   // :441-452
+                }
+                uint32_t lo = 0, hi = 0;
+                for (int t = 0; t < 6; ++t) lo |= f[t] << (5 * t);
+                for (int t = 6; t < 9; ++t) hi |= f[t] << (5 * (t - 6));
+                hi |= (inc ? CLS_INC : 0u) | (kind == SMC_KIND_GAP ? CLS_GAP : 0u);
+                cls[c_][0] = lo; cls[c_][1] = hi;
+            }
+        memcpy(&h[256], cls, sizeof cls);
+    }
     HIPCHK(hipMalloc(&c->lut, sizeof h));
     HIPCHK(hipMemcpy(c->lut, h, sizeof h, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc(&c->simple, sizeof(double) * 2 * SMC_SIMPLE_N));

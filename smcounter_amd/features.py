@@ -39,6 +39,16 @@ assert LOCUS_DTYPE.itemsize == 32
 FL_R2, FL_REV, FL_MMOK = 1, 2, 4
 LF_SAMPLED = 1                  # smc_locus.flags: host-applied down-sampling (include/smcounter_hip.h)
 USTART_DROPPED = 0x80000000
+FRAG_SLOT_MASK = 0x07FFFFFF      # frag plane: bits 0-26 fragment slot, bits 27-31 read class (smcounter_hip.h)
+FRAG_CLASS_SHIFT = 27
+
+
+def read_class(kind, rev, r2, inc, bq_ok, le20, prle):
+    """numpy version of smc_read_class (include/smcounter_hip.h): what a read adds to the tallies, as a code."""
+    kind = np.asarray(kind)
+    rev, r2, inc, bq_ok, le20, prle = (np.asarray(x).astype(np.uint32) for x in (rev, r2, inc, bq_ok, le20, prle))
+    sub = np.where(inc == 0, 1 - bq_ok, np.where(r2 == 0, 2 + le20, 4 + le20 + 2 * prle))
+    return np.where(kind == KIND_INDEL_GAP, inc, np.where(kind != KIND_BASE, 2 + 2 * rev + inc, 6 + 8 * rev + sub)).astype(np.uint32)
 KIND_SHIFT = 3
 KIND_BASE, KIND_INDEL_GAP, KIND_INS, KIND_DELSTART = 0, 1, 2, 3
 READ_ALIGN = 4
@@ -144,6 +154,10 @@ def extract_features(pb: PileupBatch, params: VcParams) -> DeviceBatch:
     bq = pb.bq.astype(np.uint32)
     meta = pb.allele.astype(np.uint32) | bq << 8 | flags << 16 | pb.mq.astype(np.uint32) << 24
     dist = d_bc | d_pr << 16
+    # read class (frag plane bits 27-31): the tally predicates evaluated with this run's parameters
+    bq_ok = pb.bq.astype(np.int64) >= params.minBQ
+    inc = (bq_ok | (kind == KIND_INDEL_GAP)) & (pb.mq.astype(np.int64) >= params.minMQ) & mm_ok      # incCond, :378
+    rclass = read_class(kind, rev, is_r2, inc, bq_ok, d_bc <= 20, d_pr <= params.primerDist)
 
     # --- per-locus counts: barcodes, fragments (allMT / allFrag, smCounter.py:482-483)
     loci = np.zeros(n_loci, LOCUS_DTYPE)
@@ -220,8 +234,6 @@ def extract_features(pb: PileupBatch, params: VcParams) -> DeviceBatch:
     # random.sample seeded with the position string.  Dropped keys are marked in umi_start (bit 31).
     if pb.umi_names is not None and n and params.ds > 0:      # (ds <= 0: usedMT = 0, Zero_Coverage anyway)
         from .py2compat import py2_downsample_barcodes
-        inc = ((pb.bq.astype(np.int64) >= params.minBQ) | (kind == KIND_INDEL_GAP)) \
-            & (pb.mq.astype(np.int64) >= params.minMQ) & mm_ok
         for l in np.nonzero(n_umi > params.ds)[0]:
             s = pb.locus_slice(int(l))
             ui = pb.umi[s][inc[s]]
@@ -237,7 +249,7 @@ def extract_features(pb: PileupBatch, params: VcParams) -> DeviceBatch:
                     umi_start[o + int(u)] |= USTART_DROPPED
             loci["flags"][l] |= LF_SAMPLED
 
-    return DeviceBatch(loci=loci, meta=plane(meta), umi=plane(pb.umi), frag=plane(slot),
+    return DeviceBatch(loci=loci, meta=plane(meta), umi=plane(pb.umi), frag=plane(slot | rclass << FRAG_CLASS_SHIFT),
                        dist=plane(dist), umi_start=umi_start, chrom=list(pb.chrom), pos=pb.pos.copy(),
                        ref=list(pb.ref), alleles=[list(t) for t in pb.alleles],
                        umi_names=None if pb.umi_names is None else [list(t) for t in pb.umi_names])

@@ -427,14 +427,16 @@ def generate_native(cfg: SynthConfig, lo: int = 0, hi: int = None, params=None, 
                     ("p_overlap", ctypes.c_double), ("p_err", ctypes.c_double), ("p_gap", ctypes.c_double),
                     ("p_ins", ctypes.c_double), ("p_delstart", ctypes.c_double), ("p_n", ctypes.c_double),
                     ("alt_locus_frac", ctypes.c_double), ("alt_af", ctypes.c_double),
-                    ("mismatch_thr", ctypes.c_double)]
+                    ("mismatch_thr", ctypes.c_double), ("min_bq", ctypes.c_int32), ("min_mq", ctypes.c_int32),
+                    ("primer_dist", ctypes.c_int32), ("pad_", ctypes.c_int32)]
 
     hi = cfg.n_loci if hi is None else hi
     params = params or params_for(cfg)
     lib = ctypes.CDLL(build.build_synth())
     lib.smc_synth_slots.restype = ctypes.c_int64
     c = Cfg(cfg.n_loci, cfg.n_umi, cfg.rpb, cfg.seed, cfg.start_pos, cfg.p_overlap, cfg.p_err, cfg.p_gap,
-            cfg.p_ins, cfg.p_delstart, cfg.p_n, cfg.alt_locus_frac, cfg.alt_af, params.mismatchThr)
+            cfg.p_ins, cfg.p_delstart, cfg.p_n, cfg.alt_locus_frac, cfg.alt_af, params.mismatchThr,
+            params.minBQ, params.minMQ, params.primerDist, 0)
     n = hi - lo
     slots = lib.smc_synth_slots(ctypes.byref(c), ctypes.c_int64(lo), ctypes.c_int64(hi))
     planes = [np.empty(slots, np.uint32) for _ in range(4)]

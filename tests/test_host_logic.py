@@ -39,11 +39,21 @@ def test_threshold_and_smt_and_ds():
     assert VcParams(mtDepth=10, maxMT=7).ds == 7
 
 
-def _check_layout(db, l):
-    """Reads of a locus: sorted barcode-major, fragment slots contiguous per barcode, umi_start consistent."""
+def _check_layout(db, l, P_LAYOUT):
+    """Reads of a locus: sorted barcode-major, fragment slots contiguous per barcode, umi_start consistent, read
+    classes consistent with the raw fields."""
     o, n = db.read_off(l), int(db.loci["n_reads"][l])
-    u, f = db.umi[o:o + n].astype(np.int64), db.frag[o:o + n].astype(np.int64)
+    u, f = db.umi[o:o + n].astype(np.int64), (db.frag[o:o + n] & features.FRAG_SLOT_MASK).astype(np.int64)
     assert (np.diff(u) >= 0).all() and (np.diff(f) >= 0).all()
+    # read class (frag bits 27-31) = smc_read_class of the raw fields under the run's parameters
+    m, d = db.meta[o:o + n], db.dist[o:o + n]
+    fl, bq, mq = (m >> 16) & 0xff, (m >> 8) & 0xff, m >> 24
+    kind = (fl >> 3) & 3
+    bq_ok = bq >= P_LAYOUT.minBQ
+    inc = (bq_ok | (kind == 1)) & (mq >= P_LAYOUT.minMQ) & ((fl & 4) != 0)
+    want = features.read_class(kind, (fl & 2) != 0, (fl & 1) != 0, inc, bq_ok, (d & 0xffff) <= 20,
+                               (d >> 16) <= P_LAYOUT.primerDist)
+    assert np.array_equal(db.frag[o:o + n] >> features.FRAG_CLASS_SHIFT, want)
     nu = int(db.loci["n_umi"][l])
     us = db.umi_start[int(db.loci["umi_off"][l]):int(db.loci["umi_off"][l]) + nu + 1]
     assert us[0] == 0 and us[-1] == n
@@ -61,12 +71,12 @@ def test_layout_of_native_generator_and_feature_extraction():
     db = synth.generate_native(cfg, 0, 50)
     assert (db.loci["n_reads"] == cfg.depth).all() and (db.loci["n_umi"] == cfg.n_umi).all()
     for l in range(db.n_loci):
-        _check_layout(db, l)
+        _check_layout(db, l, synth.params_for(cfg))
     pb = synth.generate(cfg, 0, 20)
     db2 = features.extract_features(pb, synth.params_for(cfg))
     assert (db2.loci["n_umi"] == cfg.n_umi).all() and db2.n_reads == 20 * cfg.depth
     for l in range(db2.n_loci):
-        _check_layout(db2, l)
+        _check_layout(db2, l, synth.params_for(cfg))
         # the sort is stable: reads of one fragment keep their pileup order
         s_ = pb.locus_slice(l)
         o, n = db2.read_off(l), int(db2.loci["n_reads"][l])
@@ -74,10 +84,11 @@ def test_layout_of_native_generator_and_feature_extraction():
         order = np.argsort(key, kind="stable")
         assert np.array_equal(db2.meta[o:o + n] & 0xff, pb.allele[s_][order])
     pbs, _ = synth.generate_stress(40, 5)
-    dbs = features.extract_features(pbs, VcParams(mtDepth=100, rpb=2))
+    Ps = VcParams(mtDepth=100, rpb=2, minBQ=25, minMQ=20, primerDist=7)
+    dbs = features.extract_features(pbs, Ps)
     for l in range(dbs.n_loci):
         if dbs.loci["n_reads"][l]:
-            _check_layout(dbs, l)
+            _check_layout(dbs, l, Ps)
 
 
 def test_unflagged_first_read_is_an_error():
@@ -149,7 +160,7 @@ def test_abi_library_loads_and_exports_every_declared_symbol():
     L = _lib.load()
     hdr = open(os.path.join(ROOT, "include", "smcounter_hip.h")).read()
     declared = set(re.findall(r"\b(smc_[a-z_0-9]+)\s*\(", hdr))
-    declared -= {"smc_ctx", "smc_plan"}
+    declared -= {"smc_ctx", "smc_plan", "smc_read_class"}      # (smc_read_class: static inline helper)
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert getattr(L, name) is not None
