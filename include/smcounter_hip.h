@@ -112,7 +112,8 @@ typedef struct smc_params {
  * umi_start[umi_off + u], u = 0..n_umi, is the index (relative to the locus) of barcode u's first read;
  * the last entry equals n_reads. Every barcode has at least one read. Given barcode-major reads, umi_start
  * determines the umi plane; the default kernel uses umi_start and the slot order and does not load the umi
- * plane (the sorted-stream variant, SMC_KERNEL=sorted, reads it). Checked per locus, violations flag the row
+ * plane (the sorted-stream variant, SMC_KERNEL=sorted, reads it). frag words carry the read class in bits 27-31
+ * (smc_read_class above); with it the default kernel does not load the dist plane either. Checked per locus, violations flag the row
  * SMC_ST_BAD_INPUT: frag < n_frag, allele < n_alleles, umi_start ascending and covering [0, n_reads),
  * barcode slot ranges ascending and covering [0, n_frag).
  * Base qualities are Phred values <= 126 (BAM holds 0..93); larger bytes are clamped to 126. */
