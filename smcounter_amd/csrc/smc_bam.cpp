@@ -626,7 +626,7 @@ int64_t smc_bam_planes(void* h, const char* chrom, int64_t start0, int64_t end0,
                 if (ds > 0 && !inc_seen[(size_t)u] && inc) { inc_seen[(size_t)u] = 1; inc_order.push_back(u); }
                 c_class.push_back((uint8_t)smc_read_class((int)kind, rev, r2, inc, bq_ok, (dist & 0xffffu) <= 20u,
                                                          (int)(dist >> 16) <= primer_dist));
-                c_meta.push_back((uint32_t)ai | bq << 8 | flags << 16 | (uint32_t)a.mapq << 24);
+                c_meta.push_back((uint32_t)ai | (kind == 1 ? (unsigned)min_bq : bq) << 8 | flags << 16 | (uint32_t)a.mapq << 24);   // in-deletion: minBQ, :418
                 c_umi.push_back((uint32_t)u); c_frag.push_back((uint32_t)f); c_dist.push_back(dist);
             }
             // fragment slots UMI-major, then a stable counting sort of the reads by slot

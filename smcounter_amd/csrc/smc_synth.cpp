@@ -196,7 +196,8 @@ int smc_synth_generate(const smc_synth_cfg* c, int64_t lo, int64_t hi, uint32_t*
                 Rd& r = out[i];
                 int al = r.allele;
                 if (al == 254) al = ins_id; else if (al == 253) al = dst_id;
-                meta[off + i] = (uint32_t)al | ((uint32_t)r.bq << 8) | ((uint32_t)r.flags << 16) | ((uint32_t)r.mq << 24);
+                const uint32_t bq_out = ((r.flags >> SMC_KIND_SHIFT) & 3) == SMC_KIND_GAP ? (uint32_t)c->min_bq : (uint32_t)r.bq;   // :418
+                meta[off + i] = (uint32_t)al | (bq_out << 8) | ((uint32_t)r.flags << 16) | ((uint32_t)r.mq << 24);
                 umi[off + i] = r.umi;
                 {
                     const int kind = (r.flags >> SMC_KIND_SHIFT) & 3, bq_ok = r.bq >= c->min_bq;

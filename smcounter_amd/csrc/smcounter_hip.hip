@@ -162,9 +162,9 @@ __device__ __forceinline__ long long wave_add64(long long v) {
 // for a single read (prob forced to 0.1, smCounter.py:67-68); qualities are <= 126 by the batch contract
 // (a BAM holds 0..93) and clamped to that.
 // read-class table entry (two words): nine 5-bit tally increments in SMC_T_* order (six in .x, three in .y),
-// .y bit 30 = the read enters bcDict (incCond), .y bit 31 = the read is inside a deletion
-#define CLS_INC 0x40000000u
-#define CLS_GAP 0x80000000u
+// .y bit 31 = the read enters bcDict (incCond).  (In-deletion reads need nothing special here: the batch carries
+// minBQ as their quality, smCounter.py:418.)
+#define CLS_INC 0x80000000u
 #define ST_PRESENT 0x80000000u
 #define ST_PAIRED 0x40000000u
 // raw fragment word (P1): first read in bits 0-13 (allele << 8 | quality), second in 14-27
@@ -448,6 +448,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
         for (int qb = 0; qb < n4; qb += BLOCK) {
             const int q = qb + tid;
             const uint4 cm = m4, cf = f4;
+            const bool full = 4 * (qb + BLOCK) <= n;                     // every read of this step exists
             const uint2 cpf = pf2;
             {   // prefetch the next step while this one is processed
                 const int qn = q + BLOCK;
@@ -474,24 +475,23 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
             lmask m_okk[4], m_inck[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const lmask m_valid = BAL(4 * q + k < n);                 // n4 = ceil(n/4): q < n4 follows
+                const lmask m_valid = full ? ~0ull : BAL(4 * q + k < n);  // n4 = ceil(n/4): q < n4 follows
                 m_okk[k] = m_valid & BAL(fs[k] < (uint32_t)nF) & BAL((ms[k] & 0xffu) < (uint32_t)nA) &
                            BAL((fw[k] >> SMC_FRAG_CLASS_SHIFT) < (uint32_t)SMC_N_READ_CLASS);
                 err_m |= m_valid & ~m_okk[k];
-                m_inck[k] = m_okk[k] & BAL((cw[k].y & CLS_INC) != 0u);    // incCond (:378), evaluated by the host
+                m_inck[k] = m_okk[k] & BAL((int)cw[k].y < 0);             // incCond (:378), evaluated by the host
             }
             // inclusion of the read just before the quad: the neighbour lane's fourth read, or lane 0's loaded one
-            lmask m_inc_prev = (m_inck[3] << 1) | (BAL((cwp.y & CLS_INC) != 0u) & BAL(q > 0) & 1ull);
+            lmask m_inc_prev = (m_inck[3] << 1) | (BAL((int)cwp.y < 0) & BAL(q > 0) & 1ull);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const uint32_t mw = ms[k], f = fs[k];
                 const uint32_t a = mw & 0xffu;
                 const lmask m_ok = m_okk[k], m_inc = m_inck[k];
                 const lmask m_ref = m_ok & BAL(a == refa);
-                const lmask m_gap = BAL((int)cw[k].y < 0);
                 n_inc_s += (uint32_t)__popcll(m_inc);
                 acc0 += LANES(m_ref) ? cw[k].x : 0u;
-                acc1 += LANES(m_ref) ? (cw[k].y & 0x7FFFu) : 0u;
+                acc1 += LANES(m_ref) ? cw[k].y : 0u;                      // (the flag bit above the fields just wraps)
                 lmask nr = m_ok & ~m_ref;
                 if (nr) {
                     // stray reads (sequencing errors, indel alleles): the class's increments, one tally at a time
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SMC_WAVES
                     const lmask m_ovf = m_ok & m_same1 & BAL(f == fp2);
                     ovf_any |= m_ovf;
                     if (LANES(m_inc | m_ovf)) {
-                        uint32_t bq_eff = LANES(m_gap) ? (uint32_t)P.min_bq : ((mw >> 8) & 0xffu);         // :418
+                        uint32_t bq_eff = (mw >> 8) & 0xffu;              // (in-deletion reads carry minBQ, :418)
                         bq_eff = bq_eff < PIDX_UNPAIRED ? bq_eff : PIDX_UNPAIRED - 1u;   // contract: quality <= 126
                         uint32_t w = (a << 8) | bq_eff;
                         w = LANES(m_second) ? (w << 14) | FW_HAS2 : w | FW_HAS1;
@@ -1854,7 +1854,7 @@ int smc_create(int device, smc_ctx** out) {
                 uint32_t lo = 0, hi = 0;
                 for (int t = 0; t < 6; ++t) lo |= f[t] << (5 * t);
                 for (int t = 6; t < 9; ++t) hi |= f[t] << (5 * (t - 6));
-                hi |= (inc ? CLS_INC : 0u) | (kind == SMC_KIND_GAP ? CLS_GAP : 0u);
+                hi |= inc ? CLS_INC : 0u;
                 cls[c_][0] = lo; cls[c_][1] = hi;
             }
         memcpy(&h[256], cls, sizeof cls);

@@ -151,7 +151,8 @@ def extract_features(pb: PileupBatch, params: VcParams) -> DeviceBatch:
                           "error-probability table stops at %d" % (int(pb.bq.max()), MAX_BQ, MAX_BQ))
     flags = (is_r2.astype(np.uint32) * FL_R2 | rev.astype(np.uint32) * FL_REV
              | mm_ok.astype(np.uint32) * FL_MMOK | kind << KIND_SHIFT)
-    bq = pb.bq.astype(np.uint32)
+    # in-deletion reads get minBQ as their quality (smCounter.py:418) already here
+    bq = np.where(kind == KIND_INDEL_GAP, np.uint32(params.minBQ), pb.bq.astype(np.uint32)).astype(np.uint32)
     meta = pb.allele.astype(np.uint32) | bq << 8 | flags << 16 | pb.mq.astype(np.uint32) << 24
     dist = d_bc | d_pr << 16
     # read class (frag plane bits 27-31): the tally predicates evaluated with this run's parameters
