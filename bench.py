@@ -5,7 +5,9 @@ Metric (BASELINE.json): loci/s at fixed read-depth x reads-per-UMI.  Workload at
 BASELINE.json configs[2] "synthetic 200k loci, 3000x depth, 50 UMIs/locus, 60 rpb" PER GPU (weak
 scaling: rank r calls loci [r*200k, (r+1)*200k) of the same seeded config), inputs resident in HBM
 before the timed region.  A step = one pass of the hot path (k_call_loci bins + k_filter_loci) over
-the rank's batch, followed, for N > 1, by the gather of the fixed-width rows to rank 0 (RCCL).
+the rank's batch, followed, for N > 1, by the gather of the fixed-width rows to rank 0 (RCCL; the gather of a
+step overlaps the next step's kernels, two row buffers per rank - every step's rows are gathered inside the timed
+region).
 
 Prints ONE JSON line on rank 0 (see the task contract): value = loci of all ranks / max-over-ranks
 time; roofline = algorithmic bytes (16 B/read + 360 B/locus) of the dominant kernel
@@ -56,7 +58,9 @@ def main():
     from smcounter_amd import engine
     from smcounter_amd import dist as smcdist
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # (SMC_BENCH_FORCE_DIST=1 under a 1-process torch.distributed.run exercises the collective path on one GPU)
+    use_dist = world > 1 or bool(os.environ.get("SMC_BENCH_FORCE_DIST"))
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -94,32 +98,47 @@ def main():
     torch.cuda.synchronize()
     t_build = time.time() - t0
 
-    gather_buf = None
-    if world > 1 and rank == 0:
-        gather_buf = [torch.empty_like(rows) for _ in range(world)]
+    # N > 1: the rows of step i travel to rank 0 (RCCL, its own stream) while step i + 1 computes - two row
+    # buffers per rank, a buffer is reused only after its gather has completed
+    row_bufs = [rows, plan.alloc_rows()] if use_dist else [rows]
+    gather_bufs = [[torch.empty_like(rows) for _ in range(world)] for _ in row_bufs] if use_dist and rank == 0 else None
+    pending = [None] * len(row_bufs)
+    n_step = [0]
 
     def step():
-        plan.run(planes, params, rows)
-        if world > 1:
-            smcdist.gather_rows(rows, gather_buf, dst=0)
+        b = n_step[0] % len(row_bufs)
+        n_step[0] += 1
+        if pending[b] is not None:
+            pending[b].wait()
+        plan.run(planes, params, row_bufs[b])
+        if use_dist:
+            pending[b] = dist.gather(row_bufs[b], gather_bufs[b] if rank == 0 else None, dst=0, async_op=True)
+
+    def drain():
+        for k, w in enumerate(pending):
+            if w is not None:
+                w.wait()
+                pending[k] = None
 
     for _ in range(a.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     plan.set_timing(min(a.steps, 64))
     torch.cuda.synchronize()
     t_start = time.perf_counter()
     for _ in range(a.steps):
         step()
+    drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
     k_ms, k_n, k_loci, k_reads = plan.kernel_ms()
     plan.set_timing(0)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -161,7 +180,7 @@ def main():
             bad = abi.compare_rows(gpu_rows, cpu["rows"], fragile=cpu["fragile"])
             out["parity_sample"] = {"loci": len(gpu_rows), "mismatches": len(bad), "detail": bad[:3]}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
