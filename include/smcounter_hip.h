@@ -192,6 +192,10 @@ int smc_locus_size(void); /* sizeof(smc_locus) */
 /* Number of gfx950 devices visible; does not initialise any of them. */
 int smc_device_count(void);
 
+/* (diagnostic, no GPU needed) the read-class table the kernel uses: out[2c], out[2c+1] for class c < 32 - nine 5-bit
+ * tally increments in SMC_T_* order (six in the first word, three in the second); second word bit 31 = incCond. */
+void smc_class_table(uint32_t* out);
+
 /* Bind a context to one device (one per process / host thread). */
 int smc_create(int device, smc_ctx** out);
 void smc_destroy(smc_ctx* ctx);

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, "libsmcounter_hip.so")
 SYMBOLS = ("smc_abi_version", "smc_last_error", "smc_row_size", "smc_locus_size", "smc_device_count",
            "smc_create", "smc_destroy", "smc_plan_create", "smc_plan_destroy", "smc_plan_info",
            "smc_plan_run", "smc_plan_set_timing", "smc_plan_kernel_ms", "smc_call_batch_host", "smc_event_create", "smc_event_record",
-           "smc_event_elapsed_ms", "smc_event_destroy")
+           "smc_event_elapsed_ms", "smc_event_destroy", "smc_class_table")
 
 
 class SmcError(RuntimeError):

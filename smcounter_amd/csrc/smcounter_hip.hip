@@ -1818,6 +1818,34 @@ int smc_device_count(void) {
     return n;
 }
 
+// read class -> what the read adds to its allele's tallies (include/smcounter_hip.h: smc_read_class).  out[2c], out[2c+1]:
+// nine 5-bit increments in SMC_T_* order (six in the first word, three in the second), second word bit 31 = incCond.
+void smc_class_table(uint32_t* out /* [64] */) {
+    uint32_t cls[32][2];
+    memset(cls, 0, sizeof cls);
+    for (int kind = 0; kind < 4; ++kind)
+        for (int bits = 0; bits < 64; ++bits) {
+            const int rev = bits & 1, r2 = (bits >> 1) & 1, inc = (bits >> 2) & 1, bq_ok = (bits >> 3) & 1,
+                      le20 = (bits >> 4) & 1, prle = (bits >> 5) & 1;
+            if (kind == SMC_KIND_BASE && inc && !bq_ok) continue;           // included implies bq >= minBQ
+            const uint32_t c_ = smc_read_class(kind, rev, r2, inc, bq_ok, le20, prle);
+            uint32_t f[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            f[SMC_T_CNT] = 1;                                                // :379,401,459
+            if (kind != SMC_KIND_GAP) f[rev ? SMC_T_REV : SMC_T_FWD] = 1;    // :386-389,408-411,454-457
+            if (kind == SMC_KIND_BASE) {
+                if (!bq_ok) f[SMC_T_LOWQ] = 1;                               // :428-429
+                if (inc && !r2) { f[SMC_T_R1N] = 1; f[SMC_T_R1LE] = (uint32_t)le20; }                  // :432-440
+                if (inc && r2) { f[SMC_T_R2N] = 1; f[SMC_T_R2BCLE] = (uint32_t)le20; f[SMC_T_R2PRLE] = (uint32_t)prle; }   // :441-452
+            }
+            uint32_t lo = 0, hi = 0;
+            for (int t = 0; t < 6; ++t) lo |= f[t] << (5 * t);
+            for (int t = 6; t < 9; ++t) hi |= f[t] << (5 * (t - 6));
+            hi |= inc ? CLS_INC : 0u;
+            cls[c_][0] = lo; cls[c_][1] = hi;
+        }
+    memcpy(out, cls, sizeof cls);
+}
+
 int smc_create(int device, smc_ctx** out) {
     if (!out) return fail(SMC_E_ARG, "smc_create: out is NULL");
     int n = 0;
@@ -1833,32 +1861,7 @@ int smc_create(int device, smc_ctx** out) {
     c->max_lds = 160 * 1024;
     double h[256 + 32];
     for (int q = 0; q < 256; ++q) h[q] = pow(10.0, -q / 10.0);   // smCounter.py:469
-    {
-        // read class -> what the read adds to its allele's tallies (include/smcounter_hip.h: smc_read_class)
-        uint32_t cls[32][2];
-        memset(cls, 0, sizeof cls);
-        for (int kind = 0; kind < 4; ++kind)
-            for (int bits = 0; bits < 64; ++bits) {
-                const int rev = bits & 1, r2 = (bits >> 1) & 1, inc = (bits >> 2) & 1, bq_ok = (bits >> 3) & 1,
-                          le20 = (bits >> 4) & 1, prle = (bits >> 5) & 1;
-                if (kind == SMC_KIND_BASE && inc && !bq_ok) continue;           // included implies bq >= minBQ
-                const uint32_t c_ = smc_read_class(kind, rev, r2, inc, bq_ok, le20, prle);
-                uint32_t f[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-                f[SMC_T_CNT] = 1;                                                // :379,401,459
-                if (kind != SMC_KIND_GAP) f[rev ? SMC_T_REV : SMC_T_FWD] = 1;    // :386-389,408-411,454-457
-                if (kind == SMC_KIND_BASE) {
-                    if (!bq_ok) f[SMC_T_LOWQ] = 1;                               // :428-429
-                    if (inc && !r2) { f[SMC_T_R1N] = 1; f[SMC_T_R1LE] = (uint32_t)le20; }                  // :432-440
-                    if (inc && r2) { f[SMC_T_R2N] = 1; f[SMC_T_R2BCLE] = (uint32_t)le20; f[SMC_T_R2PRLE] = (uint32_t)prle; }   // :441-452
-                }
-                uint32_t lo = 0, hi = 0;
-                for (int t = 0; t < 6; ++t) lo |= f[t] << (5 * t);
-                for (int t = 6; t < 9; ++t) hi |= f[t] << (5 * (t - 6));
-                hi |= inc ? CLS_INC : 0u;
-                cls[c_][0] = lo; cls[c_][1] = hi;
-            }
-        memcpy(&h[256], cls, sizeof cls);
-    }
+    smc_class_table((uint32_t*)&h[256]);
     HIPCHK(hipMalloc(&c->lut, sizeof h));
     HIPCHK(hipMemcpy(c->lut, h, sizeof h, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc(&c->simple, sizeof(double) * 2 * SMC_SIMPLE_N));

@@ -265,3 +265,36 @@ def test_batch_row_formatter_equals_the_per_row_one():
         assert fast == slow
         n += len(R)
     assert n > 600
+
+
+def test_read_class_table_matches_the_definition():
+    """The table the kernel uses (built on the host by the library) against a direct evaluation of what a read adds to
+    its allele's tallies (smCounter.py:379-459) for every combination of the seven predicates."""
+    L = _lib.load()
+    tab = (ctypes.c_uint32 * 64)()
+    L.smc_class_table(tab)
+    tab = np.array(list(tab), np.uint32).reshape(32, 2)
+    seen = set()
+    for kind in range(4):
+        for bits in range(64):
+            rev, r2, inc, bq_ok, le20, prle = [(bits >> b) & 1 for b in range(6)]
+            if kind == 0 and inc and not bq_ok:
+                continue
+            c = int(features.read_class(kind, rev, r2, inc, bq_ok, le20, prle))
+            assert 0 <= c < 22
+            seen.add(c)
+            f = [0] * 9
+            f[0] = 1
+            if kind != 1:
+                f[2 if rev else 1] = 1
+            if kind == 0:
+                f[3] = int(not bq_ok)
+                if inc and not r2:
+                    f[4], f[5] = 1, le20
+                if inc and r2:
+                    f[6], f[7], f[8] = 1, le20, prle
+            lo, hi = int(tab[c, 0]), int(tab[c, 1])
+            got = [(lo >> (5 * t)) & 31 for t in range(6)] + [(hi >> (5 * t)) & 31 for t in range(3)]
+            assert got == f, (kind, bits, c)
+            assert (hi >> 31) == inc
+    assert seen == set(range(22)) and not tab[22:].any()
