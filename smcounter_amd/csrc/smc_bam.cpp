@@ -42,6 +42,11 @@ struct Bam {
     FILE* fh = nullptr;
     std::string err;
     int io_threads = 1;                // threads inflating BGZF blocks in collect_reads
+    // streaming cursor: where the previous collect_reads found its first overlapping record - a later run on the
+    // same reference that starts at or after the previous one never needs anything before it
+    int cur_tid = -1;
+    int64_t cur_start = -1;
+    uint64_t cur_voff = 0;
     std::vector<std::string> ref_names;
     std::vector<int32_t> ref_lens;
     std::vector<std::vector<uint64_t>> lin;   // BAI linear index per reference
@@ -174,6 +179,7 @@ struct BlockStream {
     size_t pos = 0;
     bool eof = false;
     bool keep = false;             // keep consumed bytes (record offsets stay valid)
+    std::vector<std::pair<size_t, uint64_t>> blocks;   // keep mode: (offset in data, file offset) of every block
     BlockStream(Bam& bam, uint64_t voff, int nt, bool keep_all = false) : b(bam), nthreads(nt < 1 ? 1 : nt), next_coff(voff >> 16), keep(keep_all) {
         refill();
         pos = (size_t)(voff & 0xFFFF);
@@ -199,6 +205,7 @@ struct BlockStream {
             const size_t e = r.comp.size();
             r.isize = r.comp[e - 4] | (r.comp[e - 3] << 8) | (r.comp[e - 2] << 16) | ((uint32_t)r.comp[e - 1] << 24);
             r.out_off = total; total += r.isize;
+            if (keep) blocks.emplace_back(data.size() + r.out_off, next_coff);
             next_coff += bsize;
             raws.push_back(std::move(r));
         }
@@ -229,6 +236,12 @@ struct BlockStream {
         if (bad.load()) { b.err = "inflate failed"; eof = true; return false; }
         return true;
     }
+    // BAM virtual offset of the byte at data offset `o` (keep mode)
+    uint64_t voffset_of(size_t o) const {
+        size_t lo = 0, hi = blocks.size();
+        while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (blocks[mid].first <= o) lo = mid; else hi = mid; }
+        return (blocks[lo].second << 16) | (uint64_t)(o - blocks[lo].first);
+    }
     // next record body (without block_size), contiguous in memory; nullptr at the end of the file
     const uint8_t* next_record(size_t& n) {
         while (data.size() - pos < 4) if (!refill()) return nullptr;
@@ -257,6 +270,7 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::
             while (w >= 0 && iv[(size_t)w] == 0) --w;
             if (w >= 0) voff = iv[(size_t)w];
         }
+        if (tid == b.cur_tid && start0 >= b.cur_start && b.cur_voff > voff && !getenv("SMC_BAM_NO_CURSOR")) voff = b.cur_voff;
         b.err.clear();
         // 1. inflate (threads) and find the record boundaries up to the first alignment starting at or after end0
         BlockStream bs(b, voff, b.io_threads, true);
@@ -298,9 +312,15 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::
                 for (auto& x : th) x.join();
             }
         }
-        for (Aln& a : parsed) {
+        bool have_first = false;
+        for (size_t pi = 0; pi < parsed.size(); ++pi) {
+            Aln& a = parsed[pi];
             if ((a.flag & 4) || a.cigar.empty()) continue;
             if (a.end <= start0) continue;
+            if (!have_first) {                         // (its block_size word sits 4 bytes before the body)
+                have_first = true;
+                b.cur_tid = tid; b.cur_start = start0; b.cur_voff = bs.voffset_of(recs[pi].first - 4);
+            }
             // qname -> barcode / read id (smCounter.py:320-325): <readid...>:<UMI>:<x>
             const std::string& qn = a.qname;
             const size_t c1 = qn.rfind(':');
@@ -312,6 +332,7 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::
             a.pair_gid = pair_ids.emplace(bc + "\x01" + qn.substr(0, c2), (int)pair_ids.size()).first->second;
             reads.push_back(std::move(a));
         }
+        if (!have_first) { b.cur_tid = tid; b.cur_start = start0; b.cur_voff = recs.empty() ? voff : bs.voffset_of(recs.back().first - 4); }
         if (!b.err.empty()) return -2;                  // corrupt / truncated BGZF
     }
     n_bc = (int)bc_ids.size(); n_pair = (int)pair_ids.size();

@@ -285,3 +285,28 @@ def test_native_fused_planes_fixture_and_errors(tmp_path):
                                                seq="ACGT", qual=[200] * 4, nm=0)])
     with pytest.raises(features.PileupError, match="base quality"):
         list(bamio.iter_device_batches_native(p, fa, [("chrQ", "6")], P))
+
+
+def test_native_decoder_any_locus_order(tmp_path):
+    """The decoder resumes a run where the previous one found its first overlapping record (streaming cursor):
+    must not matter when the loci come out of order or jump between references."""
+    bam, fa_path, loci = _random_bam(tmp_path, 31, True)
+    fa = fasta.FastaFile(fa_path)
+    rng = np.random.RandomState(3)
+    blocks = [loci[i:i + 7] for i in range(0, len(loci), 7)]
+    order = rng.permutation(len(blocks))
+    shuffled = [l for b in order for l in blocks[b]]
+    P = VcParams(mismatchThr=4.0)
+    want = pileup.concat([b for _, b in bamio.iter_pileup_batches(bamio.BamFile(bam), fa, shuffled, max_reads=3000)])
+    dbw = features.extract_features(want, P)
+    got = list(bamio.iter_device_batches_native(bam, fa, shuffled, P, max_reads=3000, nthreads=2))
+    assert sum(b.n_loci for _, b in got) == len(shuffled)
+    off = 0
+    for _, b in got:
+        for l in range(b.n_loci):
+            o, n = b.read_off(l), int(b.loci["n_reads"][l])
+            ow = dbw.read_off(off + l)
+            assert n == int(dbw.loci["n_reads"][off + l]) and b.pos[l] == dbw.pos[off + l]
+            for k in ("meta", "umi", "frag", "dist"):
+                assert np.array_equal(getattr(b, k)[o:o + n], getattr(dbw, k)[ow:ow + n]), k
+        off += b.n_loci
