@@ -80,6 +80,26 @@ def test_huge_locus_uses_global_tables(engine0):
     assert abi.compare_rows(got, want, PI_TOL, P_TOL, fragile) == []
 
 
+def test_long_scan_and_giant_barcode(engine0):
+    """(a) a 128-thread locus scanned in more than 7 steps: the packed 5-bit tally accumulators are spilled on the
+    way; (b) a barcode with more fragments than the per-count posterior table holds (>= 4096): scored by the general
+    path although it shows one allele."""
+    cfg = synth.SynthConfig("steps8", 40, 70, 60, 1234)
+    P = synth.params_for(cfg)
+    db = synth.generate_native(cfg, 0, 40, P)
+    assert (db.loci["n_reads"] > 7 * 512).all()
+    got = engine0.call_batch_host(db, P)
+    want, fragile = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE, return_fragile=True)
+    assert abi.compare_rows(got, want, PI_TOL, P_TOL, fragile) == []
+    cfg = synth.SynthConfig("giant", 3, 2, 6500, 4321)
+    P = synth.params_for(cfg)
+    db = synth.generate_native(cfg, 0, 3, P)
+    assert (db.loci["n_frag"] > 2 * 4096).all()
+    got = engine0.call_batch_host(db, P)
+    want, fragile = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE, return_fragile=True)
+    assert abi.compare_rows(got, want, PI_TOL, P_TOL, fragile) == []
+
+
 @pytest.mark.parametrize("seed", range(40, 52))
 def test_randomised_differential(engine0, seed):
     """Random stress batches under random parameters (quality / mapping-quality cut-offs, mtDrop, barcode cap with and
