@@ -2090,15 +2090,21 @@ int smc_call_batch_host(smc_ctx* ctx, const smc_params* prm, const smc_locus* lo
     smc_row* d_rows = nullptr;
 
     auto cleanup = [&]() {
+        if (d[1] == d[0]) d[1] = nullptr;
+        if (d[3] == d[0]) d[3] = nullptr;
         for (auto q : d) (void)hipFree(q);
         (void)hipFree(d_rows);
         smc_plan_destroy(plan);
     };
+    // the default kernel reads the meta and frag planes and umi_start only (8 of the 16 bytes per read): the umi and
+    // dist planes cross PCIe only for the sorted-stream variant
     for (int k = 0; k < 5; ++k) {
+        if ((k == 1 || k == 3) && !plan->use_sorted) continue;
         hipError_t e = hipMalloc(&d[k], sizeof(uint32_t) * (size_t)(hn[k] > 0 ? hn[k] : 1));
         if (e == hipSuccess && hn[k] > 0) e = hipMemcpy(d[k], h[k], sizeof(uint32_t) * (size_t)hn[k], hipMemcpyHostToDevice);
         if (e != hipSuccess) { cleanup(); return fail(SMC_E_HIP, std::string("plane upload: ") + hipGetErrorString(e)); }
     }
+    if (!plan->use_sorted) { d[1] = d[0]; d[3] = d[0]; }    // (never dereferenced; smc_plan_run wants non-NULL)
     hipError_t e = hipMalloc(&d_rows, sizeof(smc_row) * (size_t)n_loci);
     if (e != hipSuccess) { cleanup(); return fail(SMC_E_HIP, std::string("rows alloc: ") + hipGetErrorString(e)); }
     rc = smc_plan_run(plan, prm, d[0], d[1], d[2], d[3], d[4], d_rows, nullptr);
