@@ -91,6 +91,8 @@ CONFIGS = {
     # scripts/quick_perf.py to watch the deep-locus launch classes (512 / 1024 threads, global tables)
     "X1": SynthConfig("X1", 2_000, 3600, 9, 20170420),
     "X2": SynthConfig("X2", 20_000, 600, 10, 20170421),
+    # C3's shape with a 10 % variant at 30 % of the loci: a third of the rows goes through k_filter_loci
+    "X3": SynthConfig("X3", 40_000, 50, 60, 20170422, alt_locus_frac=0.3, alt_af=0.1),
 }
 
 
