@@ -34,6 +34,8 @@ struct Aln {
     std::vector<uint8_t> qual;
     std::vector<uint32_t> cigar;   // len << 4 | op
     int32_t bc_gid, pair_gid;      // run-wide ids of the barcode and of (barcode, read id)
+    int32_t c1, c2;                // positions of the last two ':' of qname (-1: fewer than 3 fields)
+    uint64_t h_bc, h_pair;         // hashes of the barcode and of the whole <readid>:<barcode> prefix
     uint32_t n_ind, qalen, left_sp;
     uint8_t oflag;
 };
@@ -45,8 +47,8 @@ struct Bam {
     // streaming cursor: where the previous collect_reads found its first overlapping record - a later run on the
     // same reference that starts at or after the previous one never needs anything before it
     int cur_tid = -1;
-    int64_t cur_start = -1;
-    uint64_t cur_voff = 0;
+    int64_t cur_start = -1, cur_end = -1;      // checkpoint positions: start and end of the previous run
+    uint64_t cur_voff = 0, cur_voff_end = 0;   // first record with end > cur_start / with end > cur_end
     std::vector<std::string> ref_names;
     std::vector<int32_t> ref_lens;
     std::vector<std::vector<uint64_t>> lin;   // BAI linear index per reference
@@ -270,7 +272,10 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::
             while (w >= 0 && iv[(size_t)w] == 0) --w;
             if (w >= 0) voff = iv[(size_t)w];
         }
-        if (tid == b.cur_tid && start0 >= b.cur_start && b.cur_voff > voff && !getenv("SMC_BAM_NO_CURSOR")) voff = b.cur_voff;
+        if (tid == b.cur_tid && !getenv("SMC_BAM_NO_CURSOR")) {
+            if (b.cur_end >= 0 && start0 >= b.cur_end && b.cur_voff_end > voff) voff = b.cur_voff_end;
+            else if (start0 >= b.cur_start && b.cur_voff > voff) voff = b.cur_voff;
+        }
         b.err.clear();
         // 1. inflate (threads) and find the record boundaries up to the first alignment starting at or after end0
         BlockStream bs(b, voff, b.io_threads, true);
@@ -302,6 +307,20 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::
                         if (op == 0 || op == 1 || op == 7 || op == 8) a.qalen += c >> 4;
                     }
                     a.left_sp = (!a.cigar.empty() && (a.cigar[0] & 15) == 4) ? (a.cigar[0] >> 4) : 0u;
+                    {
+                        const std::string& qn = a.qname;
+                        const size_t c1 = qn.rfind(':');
+                        const size_t c2 = (c1 == std::string::npos || c1 == 0) ? std::string::npos : qn.rfind(':', c1 - 1);
+                        a.c1 = c1 == std::string::npos ? -1 : (int32_t)c1;
+                        a.c2 = c2 == std::string::npos ? -1 : (int32_t)c2;
+                        if (a.c2 >= 0) {                     // FNV-1a; equal strings are confirmed by memcmp at interning
+                            uint64_t h = 1469598103934665603ull;
+                            for (size_t k = c2 + 1; k < c1; ++k) { h ^= (uint8_t)qn[k]; h *= 1099511628211ull; }
+                            a.h_bc = h;
+                            for (size_t k = 0; k < c2; ++k) { h ^= (uint8_t)qn[k]; h *= 1099511628211ull; }
+                            a.h_pair = h;
+                        }
+                    }
                     a.oflag = (uint8_t)(((a.flag & 0x40) ? 1 : 0) | ((a.flag & 0x80) ? 2 : 0) | ((a.flag & 0x10) ? 4 : 0) | (a.has_nm ? 8 : 0));
                 }
             };
@@ -312,7 +331,11 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::
                 for (auto& x : th) x.join();
             }
         }
-        bool have_first = false;
+        bool have_first = false, have_end = false;
+        b.cur_end = -1; b.cur_voff_end = 0;
+        // interning by 64-bit hash; a hit is confirmed against the first read that produced the id
+        std::unordered_map<uint64_t, int> hb, hp;
+        std::vector<size_t> bc_rep, pair_rep;           // index into `reads` of the id's first read
         for (size_t pi = 0; pi < parsed.size(); ++pi) {
             Aln& a = parsed[pi];
             if ((a.flag & 4) || a.cigar.empty()) continue;
@@ -321,22 +344,49 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::
                 have_first = true;
                 b.cur_tid = tid; b.cur_start = start0; b.cur_voff = bs.voffset_of(recs[pi].first - 4);
             }
+            if (!have_end && a.end > end0) {           // first record a run starting at or after end0 can need
+                have_end = true;
+                b.cur_end = end0; b.cur_voff_end = bs.voffset_of(recs[pi].first - 4);
+            }
             // qname -> barcode / read id (smCounter.py:320-325): <readid...>:<UMI>:<x>
             const std::string& qn = a.qname;
-            const size_t c1 = qn.rfind(':');
-            const size_t c2 = (c1 == std::string::npos || c1 == 0) ? std::string::npos : qn.rfind(':', c1 - 1);
-            if (c2 == std::string::npos) { b.err = "read name '" + qn + "' has fewer than 3 ':' fields"; return -3; }
+            if (a.c2 < 0) { b.err = "read name '" + qn + "' has fewer than 3 ':' fields"; return -3; }
             if (a.l_seq == 0) { b.err = "alignment " + qn + " has no sequence"; return -4; }
-            const std::string bc = qn.substr(c2 + 1, c1 - c2 - 1);
-            a.bc_gid = bc_ids.emplace(bc, (int)bc_ids.size()).first->second;
-            a.pair_gid = pair_ids.emplace(bc + "\x01" + qn.substr(0, c2), (int)pair_ids.size()).first->second;
+            const size_t c1 = (size_t)a.c1, c2 = (size_t)a.c2;
+            auto same_bc = [&](const Aln& o) {
+                return (size_t)(o.c1 - o.c2) == c1 - c2 && memcmp(o.qname.data() + o.c2 + 1, qn.data() + c2 + 1, c1 - c2 - 1) == 0;
+            };
+            {
+                auto it = hb.find(a.h_bc);
+                if (it != hb.end() && same_bc(reads[bc_rep[(size_t)it->second]])) a.bc_gid = it->second;
+                else if (it == hb.end()) { a.bc_gid = (int)bc_rep.size(); hb.emplace(a.h_bc, a.bc_gid); bc_rep.push_back(reads.size()); bc_ids.emplace(qn.substr(c2 + 1, c1 - c2 - 1), a.bc_gid); }
+                else {                                   // hash collision: fall back to the string map
+                    auto r = bc_ids.emplace(qn.substr(c2 + 1, c1 - c2 - 1), (int)bc_rep.size());
+                    if (r.second) bc_rep.push_back(reads.size());
+                    a.bc_gid = r.first->second;
+                }
+            }
+            {
+                auto it = hp.find(a.h_pair);
+                const bool hit = it != hp.end() && [&] {
+                    const Aln& o = reads[pair_rep[(size_t)it->second]];
+                    return o.c2 == a.c2 && same_bc(o) && memcmp(o.qname.data(), qn.data(), c2) == 0;
+                }();
+                if (hit) a.pair_gid = it->second;
+                else if (it == hp.end()) { a.pair_gid = (int)pair_rep.size(); hp.emplace(a.h_pair, a.pair_gid); pair_rep.push_back(reads.size()); }
+                else {
+                    auto r = pair_ids.emplace(qn.substr(c2 + 1, c1 - c2 - 1) + "\x01" + qn.substr(0, c2), (int)pair_rep.size());
+                    if (r.second) pair_rep.push_back(reads.size());
+                    a.pair_gid = r.first->second;
+                }
+            }
             reads.push_back(std::move(a));
         }
+        n_bc = (int)bc_rep.size(); n_pair = (int)pair_rep.size();
         if (!have_first) { b.cur_tid = tid; b.cur_start = start0; b.cur_voff = recs.empty() ? voff : bs.voffset_of(recs.back().first - 4); }
         if (!b.err.empty()) return -2;                  // corrupt / truncated BGZF
     }
-    n_bc = (int)bc_ids.size(); n_pair = (int)pair_ids.size();
-    if (bc_names) { bc_names->assign(bc_ids.size(), std::string()); for (const auto& kv : bc_ids) (*bc_names)[(size_t)kv.second] = kv.first; }
+    if (bc_names) { bc_names->assign((size_t)n_bc, std::string()); for (const auto& kv : bc_ids) (*bc_names)[(size_t)kv.second] = kv.first; }
     return 0;
 }
 

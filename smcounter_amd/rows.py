@@ -112,7 +112,21 @@ def format_rows(rows, db, params: VcParams, refprov):
     c_allele, c_pi, c_vdp, c_vmt, c_vsm = (cand0[k].tolist() for k in ("allele", "pi", "vdp", "vmt", "vsm"))
     rnd, ff = py2_round, _fmt_float
     out = [None] * n
-    for l in range(n):
+    # (the loop allocates a few dozen short-lived strings per locus and no cycles: the cyclic collector would only
+    # rescan the rows already built, again and again)
+    import gc
+    gc_was_on = gc.isenabled()
+    gc.disable()
+    try:
+        _format_simple_rows(out, range(n), simple, rows, db, params, refprov, cols, c_allele, c_pi, c_vdp, c_vmt, c_vsm, rnd, ff)
+    finally:
+        if gc_was_on:
+            gc.enable()
+    return out
+
+
+def _format_simple_rows(out, idx, simple, rows, db, params, refprov, cols, c_allele, c_pi, c_vdp, c_vmt, c_vsm, rnd, ff):
+    for l in idx:
         if not simple[l]:
             out[l] = format_row(rows[l], db.chrom[l], db.pos[l], db.ref[l], db.alleles[l], params, refprov)
             continue
@@ -133,4 +147,3 @@ def format_rows(rows, db, params: VcParams, refprov):
              str(vsm[0]), str(vsm[1]), str(vsm[2]), str(vsm[3]),
              ff(rnd(pi[0], 2)), ff(rnd(pi[1], 2)), ff(rnd(pi[2], 2)), ff(rnd(pi[3], 2)), ";"]
         out[l] = "\t".join(f)
-    return out
