@@ -25,26 +25,35 @@ def lib():
         _LIB = ctypes.CDLL(path)
         _LIB.smc_oracle_call_batch.restype = ctypes.c_int
         _LIB.smc_oracle_call_batch_ds.restype = ctypes.c_int
+        _LIB.smc_oracle_call_batch_full.restype = ctypes.c_int
         _LIB.smc_oracle_fisher.restype = None
     return _LIB
 
 
-def call_batch(db, cparams, row_dtype, return_fragile=False):
+def call_batch(db, cparams, row_dtype, return_fragile=False, return_pi_all=False):
     """db: smcounter_amd.features.DeviceBatch; cparams: ctypes smc_params; -> structured rows
-    (and, on request, the per-locus count of barcodes whose consensus hinges on rounding).  The batch's
-    umi_start is passed along: it carries the host's down-sampling marks (SMC_LF_SAMPLED loci)."""
+    (and, on request, the per-locus count of barcodes whose consensus hinges on rounding, and the prediction index of
+    every allele key [n_loci, 64], NaN where the allele is not a key - abi.compare_rows uses it to recognise order
+    flips between PI-tied alleles that the rows themselves do not carry).  The batch's umi_start is passed along:
+    it carries the host's down-sampling marks (SMC_LF_SAMPLED loci)."""
     L = lib()
     assert L.smc_oracle_row_size() == row_dtype.itemsize
     rows = np.zeros(db.n_loci, row_dtype)
     loci = np.ascontiguousarray(db.loci)
     fragile = np.zeros(db.n_loci, np.int32)
+    pi_all = np.full((db.n_loci, 64), np.nan) if return_pi_all else None
     ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-    rc = L.smc_oracle_call_batch_ds(ctypes.byref(cparams), ptr(loci), ctypes.c_int64(db.n_loci), ptr(db.meta), ptr(db.umi),
-                                    ptr(db.frag), ptr(db.dist), ptr(np.ascontiguousarray(db.umi_start)), ptr(rows),
-                                    ptr(fragile))
+    rc = L.smc_oracle_call_batch_full(ctypes.byref(cparams), ptr(loci), ctypes.c_int64(db.n_loci), ptr(db.meta), ptr(db.umi),
+                                      ptr(db.frag), ptr(db.dist), ptr(np.ascontiguousarray(db.umi_start)), ptr(rows),
+                                      ptr(fragile), ptr(pi_all) if return_pi_all else None)
     if rc != 0:
-        raise RuntimeError("smc_oracle_call_batch_ds failed: %d" % rc)
-    return (rows, fragile) if return_fragile else rows
+        raise RuntimeError("smc_oracle_call_batch_full failed: %d" % rc)
+    out = (rows,)
+    if return_fragile:
+        out += (fragile,)
+    if return_pi_all:
+        out += (pi_all,)
+    return out if len(out) > 1 else rows
 
 
 def call_batch_mt(db, cparams, row_dtype, n_threads):

@@ -145,7 +145,8 @@ static int tie_rank(int a, int n_keys) {
  * skip the MT-count columns of the few loci that contain one. */
 static int call_locus(const smc_params* P, const smc_locus* L, const uint32_t* meta, const uint32_t* umi,
                       const uint32_t* frag, const uint32_t* dist, const uint32_t* ustart /* may be NULL */, smc_row* R,
-                      int32_t* fragile) {
+                      int32_t* fragile, double* pi_all /* may be NULL: [SMC_MAX_ALLELES], PI of every allele, NaN = not a key */) {
+    if (pi_all) for (int a = 0; a < SMC_MAX_ALLELES; ++a) pi_all[a] = NAN;
     if (fragile) *fragile = 0;
     memset(R, 0, sizeof *R);
     R->max_allele = R->second_allele = -1;
@@ -356,6 +357,7 @@ static int call_locus(const smc_params* P, const smc_locus* L, const uint32_t* m
     R->max_allele = best;
     R->second_allele = second;
     for (int k = 0; k < 4; ++k) { R->umt[k] = mtcnt[k]; R->vsm[k] = strong[k]; R->pi[k] = fin[k]; }
+    if (pi_all) for (int a = 0; a < SMC_MAX_ALLELES; ++a) if (touched[a]) pi_all[a] = fin[a];
     if (L->ref_allele < SMC_MAX_ALLELES) memcpy(R->ref_tal, tal[L->ref_allele], sizeof R->ref_tal);
     int ref = L->ref_allele;
     int alt = best == ref ? second : best;                               /* :541-542 */
@@ -379,17 +381,22 @@ static int call_locus(const smc_params* P, const smc_locus* L, const uint32_t* m
 }
 
 /* umi_start may be NULL (no host-applied down-sampling marks); otherwise the array of include/smcounter_hip.h */
-int smc_oracle_call_batch_ds(const smc_params* P, const smc_locus* loci, int64_t n_loci, const uint32_t* meta,
-                             const uint32_t* umi, const uint32_t* frag, const uint32_t* dist, const uint32_t* umi_start,
-                             smc_row* rows, int32_t* fragile) {
+int smc_oracle_call_batch_full(const smc_params* P, const smc_locus* loci, int64_t n_loci, const uint32_t* meta,
+                               const uint32_t* umi, const uint32_t* frag, const uint32_t* dist, const uint32_t* umi_start,
+                               smc_row* rows, int32_t* fragile, double* pi_all /* may be NULL: [n_loci][SMC_MAX_ALLELES] */) {
     for (int64_t l = 0; l < n_loci; ++l) {
         const smc_locus* L = &loci[l];
         if (L->n_alleles > SMC_MAX_ALLELES) return -1;
         call_locus(P, L, meta + 4 * (int64_t)L->read_off4, umi + 4 * (int64_t)L->read_off4, frag + 4 * (int64_t)L->read_off4,
                    dist + 4 * (int64_t)L->read_off4, umi_start ? umi_start + L->umi_off : NULL, &rows[l],
-                   fragile ? &fragile[l] : NULL);
+                   fragile ? &fragile[l] : NULL, pi_all ? pi_all + l * SMC_MAX_ALLELES : NULL);
     }
     return 0;
+}
+int smc_oracle_call_batch_ds(const smc_params* P, const smc_locus* loci, int64_t n_loci, const uint32_t* meta,
+                             const uint32_t* umi, const uint32_t* frag, const uint32_t* dist, const uint32_t* umi_start,
+                             smc_row* rows, int32_t* fragile) {
+    return smc_oracle_call_batch_full(P, loci, n_loci, meta, umi, frag, dist, umi_start, rows, fragile, NULL);
 }
 int smc_oracle_call_batch(const smc_params* P, const smc_locus* loci, int64_t n_loci, const uint32_t* meta,
                           const uint32_t* umi, const uint32_t* frag, const uint32_t* dist, smc_row* rows) {

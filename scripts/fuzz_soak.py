@@ -27,8 +27,8 @@ for seed in range(first, first + n):
         pb = dataclasses.replace(pb, umi_names=names)
     db = features.extract_features(pb, P)
     got = eng.call_batch_host(db, P)
-    want, fragile = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE, return_fragile=True)
-    bad = abi.compare_rows(got, want, 1e-6, 1e-6, fragile)
+    want, fragile, pi_all = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE, return_fragile=True, return_pi_all=True)
+    bad = abi.compare_rows(got, want, 1e-6, 1e-6, fragile, pi_all)
     if bad:
         bad_total += 1
         print("seed", seed, "MISMATCH", bad[:3], flush=True)

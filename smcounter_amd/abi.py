@@ -65,11 +65,12 @@ def _pi_of(row, allele):
     return None
 
 
-def near_tie_loci(a: np.ndarray, b: np.ndarray, eps=1e-9):
+def near_tie_loci(a: np.ndarray, b: np.ndarray, eps=1e-9, pi_all=None):
     """Loci where the two implementations pick maxBase / secondMaxBase differently although the
     prediction indices of the alleles they disagree on are equal to within floating-point summation
     order (|dPI| <= eps): the reference's own choice there depends on the order its dict iterates
-    barcodes (smCounter.py:506, :534), so it is not pinned."""
+    barcodes (smCounter.py:506, :534), so it is not pinned.  `pi_all` ([n_loci, 64], the CPU restatement's PI of
+    every allele key) settles alleles the rows do not carry (a non-candidate indel key)."""
     out = set()
     d = np.nonzero((a["max_allele"] != b["max_allele"]) | (a["second_allele"] != b["second_allele"]))[0]
     for i in d:
@@ -83,6 +84,11 @@ def near_tie_loci(a: np.ndarray, b: np.ndarray, eps=1e-9):
                 px = _pi_of(b[i], x)
             if py is None:
                 py = _pi_of(b[i], y)
+            if pi_all is not None:
+                if px is None and 0 <= x < 64 and pi_all[i][x] == pi_all[i][x]:
+                    px = float(pi_all[i][x])
+                if py is None and 0 <= y < 64 and pi_all[i][y] == pi_all[i][y]:
+                    py = float(pi_all[i][y])
             if px is None or py is None or abs(px - py) > eps * max(1.0, abs(px)):
                 ok = False
         if ok:
@@ -90,7 +96,7 @@ def near_tie_loci(a: np.ndarray, b: np.ndarray, eps=1e-9):
     return out
 
 
-def compare_rows(a: np.ndarray, b: np.ndarray, pi_tol=1e-6, p_tol=1e-6, fragile=None):
+def compare_rows(a: np.ndarray, b: np.ndarray, pi_tol=1e-6, p_tol=1e-6, fragile=None, pi_all=None):
     """Field-wise comparison of two row arrays: integer fields bit-exact, PI and Fisher p-values
     within tolerance.  Returns a list of human-readable mismatches (empty = equal).
 
@@ -99,7 +105,7 @@ def compare_rows(a: np.ndarray, b: np.ndarray, pi_tol=1e-6, p_tol=1e-6, fragile=
     (oracle/smc_oracle.c: a barcode whose unique-maximum test hinges on rounding)."""
     bad = []
     assert a.shape == b.shape
-    ties = near_tie_loci(a, b)
+    ties = near_tie_loci(a, b, pi_all=pi_all)
     keep = np.ones(len(a), bool)
     keep[list(ties)] = False
     firm = np.ones(len(a), bool) if fragile is None else (np.asarray(fragile) == 0)

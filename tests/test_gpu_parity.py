@@ -119,8 +119,9 @@ def test_randomised_differential(engine0, seed):
         pb = dataclasses.replace(pb, umi_names=names)     # host-side py2 down-sampling where over the cap
     db = features.extract_features(pb, P)
     got = engine0.call_batch_host(db, P)
-    want, fragile = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE, return_fragile=True)
-    assert abi.compare_rows(got, want, PI_TOL, P_TOL, fragile) == []
+    want, fragile, pi_all = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE, return_fragile=True,
+                                                  return_pi_all=True)
+    assert abi.compare_rows(got, want, PI_TOL, P_TOL, fragile, pi_all) == []
 
 
 def test_triple_alignment_fragments(engine0):

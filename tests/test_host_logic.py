@@ -298,3 +298,25 @@ def test_read_class_table_matches_the_definition():
             assert got == f, (kind, bits, c)
             assert (hi >> 31) == inc
     assert seen == set(range(22)) and not tab[22:].any()
+
+
+def test_compare_rows_recognises_ties_with_alleles_outside_the_row():
+    """Order flips between PI-tied alleles are unpinned (the reference's own order depends on its dict iteration);
+    when the tied allele is a non-candidate indel key its PI is not in the row - the CPU restatement's full PI table
+    settles it."""
+    a = np.zeros(2, abi.ROW_DTYPE)
+    a["max_allele"], a["second_allele"] = 6, 3
+    a["pi"][:, 3] = 4.799311822
+    a["cand"]["allele"] = -1
+    a["cand"]["allele"][:, 0] = 6
+    a["cand"]["pi"][:, 0] = 4.96
+    for f in ("p_sb", "p_r1", "p_r2", "p_pr"):
+        a["cand"][f] = np.nan
+    b = a.copy()
+    b["second_allele"][0] = 7
+    assert abi.compare_rows(a, b) != []                                     # unknown PI of allele 7: reported
+    pi_all = np.full((2, 64), np.nan)
+    pi_all[:, 3], pi_all[:, 6], pi_all[:, 7] = 4.799311822, 4.96, 4.799311822 + 3e-13
+    assert abi.compare_rows(a, b, pi_all=pi_all) == []                      # tie within 1e-9: order not pinned
+    pi_all[:, 7] = 4.7
+    assert abi.compare_rows(a, b, pi_all=pi_all) != []                      # a real difference is still reported
