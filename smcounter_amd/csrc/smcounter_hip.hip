@@ -1641,34 +1641,66 @@ __global__ __launch_bounds__(WAVE) void k_call_sorted(
 // ------------------------------------------------------------------------------------------
 // kernel 2: filterVariants (smCounter.py:182-269), one wave per locus, only where it applies
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double d_lchoose(double n, double k) {
-    return lgamma(n + 1.0) - lgamma(k + 1.0) - lgamma(n - k + 1.0);
+// log(n!) for an integer-valued n >= 0: Stirling's series on x = n + 1 >= 9 (truncation < 1e-12), exact constants
+// below (one log either way, unlike the general lgamma of the device library, which is several hundred instructions)
+__device__ __forceinline__ double d_lfact(double n) {
+    const double x = n + 1.0;
+    const double r = 1.0 / x, r2 = r * r;
+    const double series = r * (8.33333333333333333e-2 + r2 * (-2.77777777777777778e-3 + r2 * (7.93650793650793651e-4 +
+                          r2 * (-5.95238095238095238e-4 + r2 * 8.41750841750841751e-4))));
+    const double st = (x - 0.5) * log(x) - x + 0.918938533204672742 + series;
+    // n = 0..7: log of 1, 1, 2, 6, 24, 120, 720, 5040
+    double small = 0.0;
+    small = n == 2.0 ? 0.693147180559945309 : small;
+    small = n == 3.0 ? 1.79175946922805500 : small;
+    small = n == 4.0 ? 3.17805383034794562 : small;
+    small = n == 5.0 ? 4.78749174278204599 : small;
+    small = n == 6.0 ? 6.57925121201010100 : small;
+    small = n == 7.0 ? 8.52516136106541430 : small;
+    return n < 8.0 ? small : st;
 }
 
 // scipy.stats.fisher_exact(table) two-sided, evaluated by one wavefront: the support is cut into
-// 64 contiguous chunks, each lane anchors its chunk with one lgamma-based pmf and walks it with the
-// exact ratio pmf(k+1)/pmf(k) = (n1-k)(n-k) / ((k+1)(n2-n+k+1)).
+// 64 contiguous chunks, each lane anchors its chunk with one log-factorial-based pmf and walks it with the
+// exact ratio pmf(k+1)/pmf(k) = (n1-k)(n-k) / ((k+1)(n2-n+k+1)).  The nine log-factorials every lane needs
+// (margins, the observed table) are evaluated once, one per lane, and broadcast.
 __device__ void wave_fisher(long long a, long long b, long long c, long long d, double* orat, double* pval) {
     const int lane = threadIdx.x & 63;
     if (a + b == 0 || c + d == 0 || a + c == 0 || b + d == 0) { *orat = NAN; *pval = 1.0; return; }
     *orat = (c > 0 && b > 0) ? ((double)(a * d)) / ((double)(c * b)) : INFINITY;
     const long long n1 = a + b, n2 = c + d, n = a + c;
     const long long lo = n - n2 > 0 ? n - n2 : 0, hi = n < n1 ? n : n1;
-    const double lden = d_lchoose((double)(n1 + n2), (double)n);
-    const double pexact = exp(d_lchoose((double)n1, (double)a) + d_lchoose((double)n2, (double)(n - a)) - lden);
+    // uniform terms: lane i evaluates argument i
+    const long long args[9] = {n1, n2, n1 + n2, n, n1 + n2 - n, a, n1 - a, n - a, n2 - n + a};
+    long long mine = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) mine = lane == i ? args[i] : mine;
+    const double lf_mine = d_lfact((double)mine);
+    double u[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+        u[i] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(lf_mine), i), __builtin_amdgcn_readlane(__double2loint(lf_mine), i));
+    const double lden = u[2] - u[3] - u[4];                              // log C(n1 + n2, n)
+    const double lnum0 = u[0] + u[1] - lden;                             // log(n1!) + log(n2!) - log C(n1 + n2, n)
+    const double pexact = exp(lnum0 - u[5] - u[6] - u[7] - u[8]);
     const double thr = pexact * (1.0 + 1e-7);
     const long long len = hi - lo + 1, chunk = (len + 63) / 64;
     const long long k0 = lo + chunk * lane, k1 = (k0 + chunk - 1 < hi) ? k0 + chunk - 1 : hi;
     double p = 0.0;
     if (k0 <= hi) {
-        double pk = exp(d_lchoose((double)n1, (double)k0) + d_lchoose((double)n2, (double)(n - k0)) - lden);
+        double pk = exp(lnum0 - d_lfact((double)k0) - d_lfact((double)(n1 - k0)) - d_lfact((double)(n - k0)) -
+                        d_lfact((double)(n2 - n + k0)));
         for (long long k = k0;; ++k) {
             if (pk <= thr) p += pk;
             if (k == k1) break;
             pk *= ((double)(n1 - k) * (double)(n - k)) / ((double)(k + 1) * (double)(n2 - n + k + 1));
         }
     }
-    for (int m = 1; m < 64; m <<= 1) p += __shfl_xor(p, m);
+    p += dpp_f64<DPP_XOR1>(p); p += dpp_f64<DPP_XOR2>(p); p += dpp_f64<DPP_HALF_MIRROR>(p); p += dpp_f64<DPP_MIRROR>(p);
+    p = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(p), 0), __builtin_amdgcn_readlane(__double2loint(p), 0)) +
+        __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(p), 16), __builtin_amdgcn_readlane(__double2loint(p), 16)) +
+        __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(p), 32), __builtin_amdgcn_readlane(__double2loint(p), 32)) +
+        __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(p), 48), __builtin_amdgcn_readlane(__double2loint(p), 48));
     *pval = p < 1.0 ? p : 1.0;
 }
 
