@@ -2100,7 +2100,7 @@ int smc_plan_run(smc_plan* p, const smc_params* prm, const uint32_t* meta, const
         if (e != hipSuccess) return fail(SMC_E_HIP, std::string("k_call_loci launch: ") + hipGetErrorString(e));
         if (timed) { HIPCHK(hipEventRecord(p->ev1[slot], st)); p->n_timed++; }
     }
-    const unsigned fgrid = (unsigned)(p->n_loci < 2048 ? p->n_loci : 2048);
+    const unsigned fgrid = (unsigned)(p->n_loci < 6144 ? p->n_loci : 6144);   // 78 VGPRs: 24 one-wave workgroups per CU
     hipLaunchKernelGGL(k_filter_loci, dim3(fgrid), dim3(WAVE), 0, st, kp, p->d_loci, rows, p->d_flt_list);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SMC_E_HIP, std::string("k_filter_loci launch: ") + hipGetErrorString(e));
