@@ -10,7 +10,7 @@ ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "smcounter_hip.hip")
 LIB = os.path.join(HERE, "libsmcounter_hip.so")
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off",
-               "-I" + os.path.join(ROOT, "include")]
+               "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc")]
 
 
 def hipcc_path() -> str:
@@ -24,7 +24,8 @@ def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [SRC, os.path.join(ROOT, "include", "smcounter_hip.h")]
+    import glob
+    deps = [SRC, os.path.join(ROOT, "include", "smcounter_hip.h")] + glob.glob(os.path.join(HERE, "csrc", "*.inc"))
     return any(os.path.getmtime(d) > t for d in deps)
 
 

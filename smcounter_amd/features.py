@@ -52,7 +52,7 @@ def read_class(kind, rev, r2, inc, bq_ok, le20, prle):
 KIND_SHIFT = 3
 KIND_BASE, KIND_INDEL_GAP, KIND_INS, KIND_DELSTART = 0, 1, 2, 3
 READ_ALIGN = 4
-MAX_BQ = 126          # device contract (smcounter_hip.hip: PIDX_UNPAIRED - 1)
+MAX_BQ = 126          # device contract (csrc/device_common.inc: PIDX_UNPAIRED - 1)
 
 
 class PileupError(Exception):
