@@ -275,3 +275,16 @@ def test_spiked_variants_cut_vcf_concordance(engine0, tmp_path):
     assert len(files[0]) == len(files[1]) >= 20
     # (loci with a rounding-decided barcode may differ by one in a count column; none is expected here)
     assert (fragile > 0).sum() == 0 and files[0] == files[1]
+
+
+def test_descriptors_outside_the_buffers_are_refused(engine0):
+    from smcounter_amd import _lib
+    cfg = synth.CONFIGS["C2"]
+    P = synth.params_for(cfg)
+    db = synth.generate_native(cfg, 0, 4, P)
+    for field, val in (("read_off4", 10 ** 6), ("umi_off", 10 ** 6), ("n_reads", -1)):
+        bad = synth.generate_native(cfg, 0, 4, P)
+        bad.loci[field][2] = val
+        with pytest.raises(_lib.SmcError, match="points outside|layout contract"):
+            engine0.call_batch_host(bad, P)
+    assert (engine0.call_batch_host(db, P)["status"] == 0).all()
