@@ -288,3 +288,24 @@ def test_descriptors_outside_the_buffers_are_refused(engine0):
         with pytest.raises(_lib.SmcError, match="points outside|layout contract"):
             engine0.call_batch_host(bad, P)
     assert (engine0.call_batch_host(db, P)["status"] == 0).all()
+
+
+def test_integration_md_stub_runs_as_written(engine0):
+    """The ctypes stub INTEGRATION.md shows for smCounter.py is executed (library path pointed at the in-tree build):
+    same strings as the package's own path."""
+    import re, types
+    from conftest import ROOT
+    from smcounter_amd import _lib
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(.*?)```", text, re.S).group(1)
+    code = code.replace('ctypes.CDLL("libsmcounter_hip.so")', "ctypes.CDLL(%r)" % _lib.LIB_PATH)
+    code = "\n".join(l for l in code.split("\n") if not l.startswith("output = vc_batch_gpu("))
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    path = [p for p in golden_files() if "stress2" in p][0]
+    pb, db, P, refp, expected = load_golden(path)
+    args = types.SimpleNamespace(minBQ=P.minBQ, minMQ=P.minMQ, mtDepth=P.mtDepth, rpb=P.rpb, hpLen=P.hpLen,
+                                 mismatchThr=P.mismatchThr, mtDrop=P.mtDrop, maxMT=P.maxMT, primerDist=P.primerDist)
+    got = ns["vc_batch_gpu"](pb, args, refp)
+    want = rows.format_rows(engine0.call_batch_host(db, P), db, P, refp)
+    assert got == want and len(got) == pb.n_loci
