@@ -99,26 +99,13 @@ def main():
     t_build = time.time() - t0
 
     # N > 1: the rows of step i travel to rank 0 (RCCL, its own stream) while step i + 1 computes - two row
-    # buffers per rank, a buffer is reused only after its gather has completed
-    row_bufs = [rows, plan.alloc_rows()] if use_dist else [rows]
-    gather_bufs = [[torch.empty_like(rows) for _ in range(world)] for _ in row_bufs] if use_dist and rank == 0 else None
-    pending = [None] * len(row_bufs)
-    n_step = [0]
+    # buffers per rank, a buffer is reused only after its gather has completed (dist.RowPipeline)
+    pipe = smcdist.RowPipeline([rows, plan.alloc_rows()] if use_dist else [rows], collective=use_dist)
 
     def step():
-        b = n_step[0] % len(row_bufs)
-        n_step[0] += 1
-        if pending[b] is not None:
-            pending[b].wait()
-        plan.run(planes, params, row_bufs[b])
-        if use_dist:
-            pending[b] = dist.gather(row_bufs[b], gather_bufs[b] if rank == 0 else None, dst=0, async_op=True)
+        pipe.step(lambda buf: plan.run(planes, params, buf))
 
-    def drain():
-        for k, w in enumerate(pending):
-            if w is not None:
-                w.wait()
-                pending[k] = None
+    drain = pipe.drain
 
     for _ in range(a.warmup):
         step()

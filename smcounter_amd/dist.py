@@ -92,3 +92,42 @@ def init_from_env():
         else:
             dist.init_process_group(backend)
     return rank, local_rank, world
+
+
+class RowPipeline(object):
+    """Double-buffered "compute rows, gather them to rank 0" loop: the gather of step i (asynchronous collective)
+    overlaps the computation of step i + 1; a row buffer is reused only after its gather has completed.
+    `bufs`: this rank's row buffers (>= 1 tensors of equal size); `produce(buf)` enqueues the work that fills one.
+    With `world == 1` (no process group) it degenerates to calling `produce`."""
+
+    def __init__(self, bufs, collective: bool, dst: int = 0):
+        self.bufs = list(bufs)
+        self.collective = collective
+        self.dst = dst
+        self.pending = [None] * len(self.bufs)
+        self.n = 0
+        self.recv = None
+        if collective:
+            import torch
+            import torch.distributed as dist
+            self.rank, self.world = dist.get_rank(), dist.get_world_size()
+            if self.rank == dst:
+                self.recv = [[torch.empty_like(b) for _ in range(self.world)] for b in self.bufs]
+
+    def step(self, produce):
+        b = self.n % len(self.bufs)
+        self.n += 1
+        if self.pending[b] is not None:
+            self.pending[b].wait()
+        produce(self.bufs[b])
+        if self.collective:
+            import torch.distributed as dist
+            self.pending[b] = dist.gather(self.bufs[b], self.recv[b] if self.rank == self.dst else None, dst=self.dst,
+                                          async_op=True)
+        return b
+
+    def drain(self):
+        for k, w in enumerate(self.pending):
+            if w is not None:
+                w.wait()
+                self.pending[k] = None

@@ -125,3 +125,43 @@ def test_two_rank_command_line_writes_the_single_process_files(tmp_path):
     got = open(str(tmp_path / "dist.smCounter.all.txt")).read().split("\n")[1:-1]
     assert got == want and len(got) == len(loci)
     assert os.path.getsize(str(tmp_path / "dist.smCounter.cut.vcf")) > 0
+
+
+def _pipe_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    from smcounter_amd import dist
+    bufs = [torch.zeros(64, dtype=torch.uint8), torch.zeros(64, dtype=torch.uint8)]
+    pipe = dist.RowPipeline(bufs, collective=True)
+    seen = []
+    for i in range(5):
+        b = pipe.step(lambda buf, i=i: buf.fill_(10 * i + rank))
+        seen.append(b)
+    pipe.drain()
+    if rank == 0:
+        # buffers alternate; after the drain rank 0 holds every rank's rows of the last two steps
+        got = {b: [int(t[0]) for t in pipe.recv[b]] for b in (0, 1)}
+        q.put((seen, got))
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_row_pipeline_overlaps_and_keeps_order():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pipe_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    seen, got = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert seen == [0, 1, 0, 1, 0]
+    assert got == {0: [40, 41], 1: [30, 31]}            # step 4 went through buffer 0, step 3 through buffer 1
