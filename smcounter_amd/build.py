@@ -64,7 +64,22 @@ def build_bam(force: bool = False) -> str:
     return BAM_LIB
 
 
+ROWFMT_SRC = os.path.join(HERE, "csrc", "smc_rowfmt.cpp")
+ROWFMT_LIB = os.path.join(HERE, "libsmc_rowfmt.so")
+
+
+def build_rowfmt(force: bool = False) -> str:
+    """Native printer of the row's numeric columns (plain g++)."""
+    hdr = os.path.join(ROOT, "include", "smcounter_hip.h")
+    if force or not os.path.exists(ROWFMT_LIB) or \
+            max(os.path.getmtime(ROWFMT_SRC), os.path.getmtime(hdr)) > os.path.getmtime(ROWFMT_LIB):
+        subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off",
+                               "-I" + os.path.join(ROOT, "include"), "-o", ROWFMT_LIB, ROWFMT_SRC])
+    return ROWFMT_LIB
+
+
 if __name__ == "__main__":
     print(build_hip(force=True))
     print(build_synth(force=True))
     print(build_bam(force=True))
+    print(build_rowfmt(force=True))

@@ -48,18 +48,13 @@ def filter_string(cand, chrom, pos, ref, alt, params: VcParams, refprov) -> str:
     return ";" + "".join(name + ";" for bit, name in abi.FILTER_NAMES if bits & bit)
 
 
-def format_row(row, chrom: str, pos, orig_ref: str, alleles, params: VcParams, refprov) -> str:
-    pos = str(int(pos))
-    st = int(row["status"])
-    if st & abi.ST_BAD_INPUT:
-        raise RowError("locus %s:%s: batch violates the layout contract (ids out of range)" % (chrom, pos))
-    if (st & 0xff) == abi.ST_ZERO_COVERAGE:
-        return "\t".join([chrom, pos, orig_ref] + [""] * 41 + ["Zero_Coverage"])
+def _head_and_filter(row, chrom: str, pos: str, orig_ref: str, alleles, params: VcParams, refprov):
+    """CHROM..TYPE, FILTER and which candidate the numeric columns are printed from (:541-573)."""
     c0 = row["cand"][0]
     orig_alt = alleles[int(c0["allele"])]
     ref, alt, vtype = convert_to_vcf(orig_ref, orig_alt)
     fltr = filter_string(c0, chrom, pos, ref, alt, params, refprov)
-    chosen = c0
+    chosen = 0
     if row["biallelic"]:
         c1 = row["cand"][1]
         ref2, alt2, vtype2 = convert_to_vcf(orig_ref, alleles[int(c1["allele"])])
@@ -68,7 +63,19 @@ def format_row(row, chrom: str, pos, orig_ref: str, alleles, params: VcParams, r
             alt = alt + "," + alt2
             vtype = vtype.lower() + "," + vtype2.lower()
         elif fltr != ";" and fltr2 == ";":
-            alt, fltr, chosen = alt2, fltr2, c1
+            alt, fltr, chosen = alt2, fltr2, 1
+    return ref, alt, vtype, fltr, chosen
+
+
+def format_row(row, chrom: str, pos, orig_ref: str, alleles, params: VcParams, refprov) -> str:
+    pos = str(int(pos))
+    st = int(row["status"])
+    if st & abi.ST_BAD_INPUT:
+        raise RowError("locus %s:%s: batch violates the layout contract (ids out of range)" % (chrom, pos))
+    if (st & 0xff) == abi.ST_ZERO_COVERAGE:
+        return "\t".join([chrom, pos, orig_ref] + [""] * 41 + ["Zero_Coverage"])
+    ref, alt, vtype, fltr, ci = _head_and_filter(row, chrom, pos, orig_ref, alleles, params, refprov)
+    chosen = row["cand"][ci]
     cvg, used = int(row["cvg"]), int(row["used_mt"])
     dp = [int(v) for v in row["dp"]]
     umt = [int(v) for v in row["umt"]]
@@ -94,19 +101,91 @@ def _fmt_float(x: float) -> str:
     return s
 
 
-def format_rows(rows, db, params: VcParams, refprov):
-    """`format_row` over a batch.  Loci whose candidate goes through no filter and is not bi-allelic (nearly all
-    of a panel) take a column-wise path - the structured array is unpacked once into Python lists instead of one
-    numpy field access per value; the others go through `format_row`.  Same strings either way
-    (tests/test_host_logic.py compares the two on the golden loci)."""
+_ROWFMT = None
+
+
+def _rowfmt():
+    """libsmc_rowfmt.so (csrc/smc_rowfmt.cpp, include/smcounter_host.h), built on first use."""
+    global _ROWFMT
+    if _ROWFMT is None:
+        import ctypes as C
+        from . import build
+        L = C.CDLL(build.build_rowfmt())
+        L.smc_rowfmt_stride.restype = C.c_int
+        L.smc_format_tails.restype = C.c_int64
+        L.smc_format_tails.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        _ROWFMT = L
+    return _ROWFMT
+
+
+def format_tails(rows, chosen=None):
+    """Columns DP..PI_C of every row, printed by the native formatter (py2 rounding and float printing); '' for the
+    rows it leaves to the caller (status != 0, chosen < 0, out-of-range values)."""
+    import numpy as np
     n = len(rows)
     if n == 0:
         return []
-    st = rows["status"].tolist()
+    L = _rowfmt()
+    rows = np.ascontiguousarray(rows)
+    assert rows.dtype.itemsize == 432
+    buf = np.empty(n * L.smc_rowfmt_stride(), np.uint8)
+    ch = None if chosen is None else np.ascontiguousarray(chosen, np.int8)
+    nb = L.smc_format_tails(rows.ctypes.data, None if ch is None else ch.ctypes.data, n, buf.ctypes.data)
+    return buf[:nb - 1].tobytes().decode("ascii").split("\n")
+
+
+def format_rows(rows, db, params: VcParams, refprov, native: bool = True):
+    """`format_row` over a batch.  The numeric columns (39 of the 45) of every callable locus are printed by the
+    native formatter in one call (`format_tails`); Python adds CHROM..TYPE and FILTER.  Loci whose candidate goes
+    through a filter or is bi-allelic (few) first get their FILTER / bi-allelic decision here (it needs the
+    reference sequence), which also selects the candidate the numeric columns are printed from.  Same strings as
+    `format_row` either way (tests/test_host_logic.py compares them on the golden loci and on random rows);
+    `native=False` keeps everything in Python."""
+    import numpy as np
+    n = len(rows)
+    if n == 0:
+        return []
+    status = rows["status"]
     cand0 = rows["cand"][:, 0]
-    simple = ((rows["status"] & 0xff) == 0) & ((rows["status"] & abi.ST_BAD_INPUT) == 0) & (rows["biallelic"] == 0) \
-        & (cand0["flt_applied"] == 0)
+    callable_ = ((status & 0xff) == 0) & ((status & abi.ST_BAD_INPUT) == 0)
+    simple = callable_ & (rows["biallelic"] == 0) & (cand0["flt_applied"] == 0)
+    if not native:
+        return _format_rows_py(rows, db, params, refprov, simple.tolist())
+    out = [None] * n
+    chosen = np.where(callable_, 0, -1).astype(np.int8)
+    heads = {}
+    pos_s = [str(int(p)) for p in (db.pos.tolist() if hasattr(db.pos, "tolist") else db.pos)]
+    for l in np.flatnonzero(callable_ & ~simple).tolist():
+        ref, alt, vtype, fltr, ci = _head_and_filter(rows[l], db.chrom[l], pos_s[l], db.ref[l], db.alleles[l], params, refprov)
+        chosen[l] = ci
+        heads[l] = ("\t".join((db.chrom[l], pos_s[l], ref, alt, vtype)), fltr)
+    tails = format_tails(rows, chosen)
+    c_allele = cand0["allele"].tolist()
     simple = simple.tolist()
+    chrom, refs, alleles = db.chrom, db.ref, db.alleles
+    for l in range(n):
+        t = tails[l]
+        if not t:                                   # Zero_Coverage / bad input / out of the native printer's range
+            out[l] = format_row(rows[l], chrom[l], db.pos[l], refs[l], alleles[l], params, refprov)
+        elif simple[l]:
+            r = refs[l]
+            a = alleles[l][c_allele[l]]
+            if len(a) == 1:                         # convert_to_vcf, SNP case inlined
+                out[l] = chrom[l] + "\t" + pos_s[l] + "\t" + r + "\t" + a + "\tSNP\t" + t + "\t;"
+            else:
+                ref, alt, vtype = convert_to_vcf(r, a)
+                out[l] = "\t".join((chrom[l], pos_s[l], ref, alt, vtype, t, ";"))
+        else:
+            h, fltr = heads[l]
+            out[l] = h + "\t" + t + "\t" + fltr
+    return out
+
+
+def _format_rows_py(rows, db, params: VcParams, refprov, simple):
+    """The batch formatter without the native library: column-wise for the simple loci - the structured array is
+    unpacked once into Python lists instead of one numpy field access per value."""
+    n = len(rows)
+    cand0 = rows["cand"][:, 0]
     cols = {k: rows[k].tolist() for k in ("cvg", "all_frag", "all_mt", "used_frag", "used_mt", "mt3", "mt5", "mt7", "mt10",
                                           "dp", "umt", "vsm", "pi")}
     c_allele, c_pi, c_vdp, c_vmt, c_vsm = (cand0[k].tolist() for k in ("allele", "pi", "vdp", "vmt", "vsm"))

@@ -260,11 +260,96 @@ def test_batch_row_formatter_equals_the_per_row_one():
     for path in golden_files():
         pb, db, P, refp, expected = load_golden(path)
         R = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE)
-        fast = rows.format_rows(R, db, P, refp)
+        fast = rows.format_rows(R, db, P, refp)                      # numeric columns from libsmc_rowfmt.so
+        py = rows.format_rows(R, db, P, refp, native=False)
         slow = [rows.format_row(R[l], db.chrom[l], db.pos[l], db.ref[l], db.alleles[l], P, refp) for l in range(len(R))]
         assert fast == slow
+        assert py == slow
         n += len(R)
     assert n > 600
+
+
+def test_native_number_printer_equals_py2_rounding_and_str():
+    """smc_format_tails against py2_round + py2_str on random rows, with the values that separate CPython 2's round
+    from this interpreter's: exact ties (odd / 2^(n+1)), values one ulp either side of a tie, negative zero, huge and
+    non-finite values (left to the caller), zero denominators."""
+    import math
+    from smcounter_amd.py2compat import py2_round, py2_str, _py2_round_exact
+    rng = np.random.default_rng(77)
+    n = 4000
+    R = np.zeros(n, abi.ROW_DTYPE)
+    for k in ("cvg", "used_mt"):
+        R[k] = rng.integers(1, 5000, n)
+    for k in ("all_frag", "all_mt", "used_frag", "mt3", "mt5", "mt7", "mt10"):
+        R[k] = rng.integers(0, 100000, n)
+    for k in ("dp", "umt", "vsm"):
+        R[k] = rng.integers(0, 5000, (n, 4))
+    # power-of-two denominators make exact quarter / eighth ... fractions: ties of the 4-decimal columns
+    R["cvg"][:600] = 2 ** rng.integers(0, 12, 600)
+    R["used_mt"][:600] = 2 ** rng.integers(0, 12, 600)
+    pi = rng.normal(0, 50, (n, 4))
+    ties2 = (2 * rng.integers(-4000, 4000, (n, 4)) + 1) / 8.0                 # odd / 2^3: ties at 2 decimals
+    pick = rng.random((n, 4))
+    pi = np.where(pick < 0.3, ties2, pi)
+    pi = np.where((pick >= 0.3) & (pick < 0.4), np.nextafter(ties2, np.inf), pi)
+    pi = np.where((pick >= 0.4) & (pick < 0.5), np.nextafter(ties2, -np.inf), pi)
+    pi = np.where((pick >= 0.5) & (pick < 0.55), rng.integers(-3, 3, (n, 4)) / 100.0 * 1.0000000001, pi)
+    R["pi"] = pi
+    R["pi"][5] = [-0.0, -0.004, 0.005, -0.005]
+    R["pi"][6] = [99999999.994, 1e8, -1e9, 12345678.125]
+    R["pi"][7] = [np.inf, -np.inf, np.nan, 1.0]
+    for c in (0, 1):
+        R["cand"]["pi"][:, c] = rng.permuted(pi[:, c])
+        for k in ("vdp", "vmt", "vsm"):
+            R["cand"][k][:, c] = rng.integers(0, 5000, n)
+    R["status"][10] = abi.ST_ZERO_COVERAGE
+    R["status"][11] = abi.ST_BAD_INPUT
+    R["status"][12] = abi.ST_DOWNSAMPLED                               # still printed
+    R["cvg"][13] = 0
+    chosen = rng.integers(0, 2, n).astype(np.int8)
+    chosen[14] = -1
+    tails = rows.format_tails(R, chosen)
+    assert len(tails) == n
+
+    def want(l):
+        r, c = R[l], R["cand"][l][int(chosen[l])]
+        cvg, used = int(r["cvg"]), int(r["used_mt"])
+        v = [cvg, int(r["all_frag"]), int(r["all_mt"]), int(r["used_frag"]), used, py2_round(float(c["pi"]), 2),
+             int(c["vdp"]), py2_round(1.0 * int(c["vdp"]) / cvg, 4), int(c["vmt"]), py2_round(1.0 * int(c["vmt"]) / used, 4),
+             int(c["vsm"])]
+        v += [int(x) for x in r["dp"]] + [py2_round(1.0 * int(x) / cvg, 4) for x in r["dp"]]
+        v += [int(r["mt3"]), int(r["mt5"]), int(r["mt7"]), int(r["mt10"])]
+        v += [int(x) for x in r["umt"]] + [py2_round(1.0 * int(x) / used, 4) for x in r["umt"]]
+        v += [int(x) for x in r["vsm"]] + [py2_round(float(x), 2) for x in r["pi"]]
+        return "\t".join(py2_str(x) for x in v)
+
+    n_cmp = 0
+    for l in range(n):
+        if l in (10, 11, 13, 14):
+            assert tails[l] == ""
+            continue
+        if l == 6:
+            assert tails[l] == ""                                      # |value| >= 1e8: left to the Python formatter
+            continue
+        assert tails[l] == want(l), l
+        n_cmp += 1
+    assert n_cmp == n - 5
+    assert tails[5].endswith("-0.0\t-0.0\t0.01\t-0.01")
+    assert tails[7].endswith("inf\t-inf\tnan\t1.0")
+    # the fast rounding itself against the exact decimal model, on the separating values
+    for x in list(ties2[:200].ravel()) + list(np.nextafter(ties2[:200], np.inf).ravel()):
+        assert py2_round(float(x), 2) == _py2_round_exact(float(x), 2)
+
+
+def test_host_libraries_export_every_symbol_of_the_host_header():
+    from smcounter_amd import build
+    hdr = open(os.path.join(ROOT, "include", "smcounter_host.h")).read()
+    declared = set(re.findall(r"\b(smc_[a-z_0-9]+)\s*\(", hdr)) - {"smc_planes_alloc"}
+    bam, fmt = ctypes.CDLL(build.build_bam()), ctypes.CDLL(build.build_rowfmt())
+    assert len(declared) >= 14
+    for name in declared:
+        lib = fmt if name in ("smc_rowfmt_stride", "smc_format_tails") else bam
+        assert getattr(lib, name) is not None, name
 
 
 def test_read_class_table_matches_the_definition():
