@@ -582,9 +582,12 @@ class NativeBam(object):
                 k += int(n_keys[l])
         return tables
 
-    def planes_run(self, chrom: str, lo: int, hi: int, max_reads: int, params, refseq: str, nthreads: int, fasta):
+    def planes_run(self, chrom: str, lo: int, hi: int, max_reads: int, params, refseq: str, nthreads: int, fasta,
+                   arena=None, arena_off: int = 0):
         """Fused decode + feature extraction of a run -> (n loci, 4 planes, umi_start, LOCUS_DTYPE array,
-        allele tables); offsets in the descriptors are relative to this run."""
+        allele tables); offsets in the descriptors are relative to this run.  With `arena` (four uint32 arrays) the
+        planes are written at `arena_off` of those when they fit (views are returned: a batch of several runs then
+        needs no concatenation), into fresh arrays otherwise."""
         import ctypes as C
         from .features import LOCUS_DTYPE, PileupError
         done, n_slots, n_us = C.c_int64(0), C.c_int64(0), C.c_int64(0)
@@ -592,7 +595,10 @@ class NativeBam(object):
         got = {}
 
         def alloc(ctx, ns, nl_, out):                    # the library writes straight into these arrays
-            got["planes"] = [np.empty(ns, np.uint32) for _ in range(4)]
+            if arena is not None and arena_off + ns <= len(arena[0]):
+                got["planes"] = [a[arena_off:arena_off + ns] for a in arena]
+            else:
+                got["planes"] = [np.empty(ns, np.uint32) for _ in range(4)]
             got["loci"] = np.empty(nl_, LOCUS_DTYPE)
             for k in range(4):
                 out[k] = got["planes"][k].ctypes.data
@@ -661,6 +667,9 @@ def iter_pileup_batches_native(path: str, fasta, loci: Sequence[Tuple[str, str]]
     bam.close()
 
 
+_ARENA_SLACK = 65536          # room for the overshoot of a batch's last locus and the 4-read padding (tests shrink it)
+
+
 def iter_device_batches_native(path: str, fasta, loci: Sequence[Tuple[str, str]], params, max_reads: int = 2_000_000,
                                nthreads: int = 0):
     """BAM -> `features.DeviceBatch` chunks in one native pass (decode, per-read features, barcode-major
@@ -674,6 +683,11 @@ def iter_device_batches_native(path: str, fasta, loci: Sequence[Tuple[str, str]]
         P, US, LC = [[] for _ in range(4)], [], []
         chroms, poss, refs, tables = [], [], [], []
         total = slots = n_us = 0
+        # the runs of a batch are written one after the other into one set of arrays (untouched pages cost nothing);
+        # a run that does not fit - the last locus of a batch may overshoot max_reads - gets its own arrays and the
+        # batch is concatenated as before
+        arena = [np.empty(max_reads + (max_reads >> 3) + _ARENA_SLACK, np.uint32) for _ in range(4)]
+        in_arena = True
         while i < n and total < max_reads:
             chrom = loci[i][0]
             j = i
@@ -682,7 +696,9 @@ def iter_device_batches_native(path: str, fasta, loci: Sequence[Tuple[str, str]]
                 j += 1
             lo, hi = int(loci[i][1]) - 1, int(loci[j][1])
             run_ref = fasta.fetch(chrom, lo, hi).upper()
-            nl, planes, ustart, lc, tb = bam.planes_run(chrom, lo, hi, max_reads - total, params, run_ref, nthreads, fasta)
+            nl, planes, ustart, lc, tb = bam.planes_run(chrom, lo, hi, max_reads - total, params, run_ref, nthreads, fasta,
+                                                        arena if in_arena else None, slots)
+            in_arena = in_arena and (len(planes[0]) == 0 or planes[0].base is arena[0])
             lc["read_off4"] += slots // 4
             lc["umi_off"] += n_us
             for k in range(4):
@@ -698,6 +714,8 @@ def iter_device_batches_native(path: str, fasta, loci: Sequence[Tuple[str, str]]
             tables += tb
             i += nl
         cat = lambda parts: parts[0] if len(parts) == 1 else np.concatenate(parts)
+        if in_arena:
+            P = [[a[:slots]] for a in arena]
         yield first, DeviceBatch(loci=cat(LC), meta=cat(P[0]), umi=cat(P[1]), frag=cat(P[2]), dist=cat(P[3]),
                                  umi_start=cat(US), chrom=chroms, pos=np.array(poss, np.int64), ref=refs, alleles=tables)
     bam.close()

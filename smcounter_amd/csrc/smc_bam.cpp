@@ -182,7 +182,9 @@ struct BlockStream {
     bool eof = false;
     bool keep = false;             // keep consumed bytes (record offsets stay valid)
     std::vector<std::pair<size_t, uint64_t>> blocks;   // keep mode: (offset in data, file offset) of every block
-    BlockStream(Bam& bam, uint64_t voff, int nt, bool keep_all = false) : b(bam), nthreads(nt < 1 ? 1 : nt), next_coff(voff >> 16), keep(keep_all) {
+    uint64_t soft_stop = ~0ull;    // hint: file offset beyond which the caller expects to need (almost) nothing
+    BlockStream(Bam& bam, uint64_t voff, int nt, bool keep_all = false, uint64_t stop_hint = ~0ull)
+        : b(bam), nthreads(nt < 1 ? 1 : nt), next_coff(voff >> 16), keep(keep_all), soft_stop(stop_hint) {
         refill();
         pos = (size_t)(voff & 0xFFFF);
         if (pos > data.size()) pos = data.size();
@@ -195,6 +197,7 @@ struct BlockStream {
         std::vector<Raw> raws;
         if (fseeko(b.fh, (off_t)next_coff, SEEK_SET) != 0) { eof = true; return false; }
         size_t total = 0;
+        int past = 0;
         for (int k = 0; k < batch; ++k) {
             uint8_t hdr[18];
             if (fread(hdr, 1, 18, b.fh) != 18) { eof = true; break; }
@@ -210,6 +213,7 @@ struct BlockStream {
             if (keep) blocks.emplace_back(data.size() + r.out_off, next_coff);
             next_coff += bsize;
             raws.push_back(std::move(r));
+            if (next_coff > soft_stop && ++past >= 2) break;      // (a hint only: the caller refills again if it must)
         }
         if (raws.empty()) return false;
         const size_t base = data.size();
@@ -228,7 +232,7 @@ struct BlockStream {
                 inflateEnd(&zs);
             }
         };
-        const int T = std::min<int>(nthreads, (int)raws.size());
+        const int T = std::min<int>(nthreads, ((int)raws.size() + 3) / 4);   // >= 4 blocks (~1 ms) per thread started
         if (T <= 1) work();
         else {
             std::vector<std::thread> th;
@@ -277,8 +281,16 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::
             else if (start0 >= b.cur_start && b.cur_voff > voff) voff = b.cur_voff;
         }
         b.err.clear();
+        // where the linear index says the alignments of the 16 kb window after end0's begin: nothing this run needs
+        // lies (much) beyond it, so the stream does not inflate further ahead than that
+        uint64_t stop_hint = ~0ull;
+        if ((size_t)tid < b.lin.size()) {
+            const auto& iv = b.lin[(size_t)tid];
+            for (size_t w = (size_t)(end0 >> 14) + 1; w < iv.size(); ++w)
+                if (iv[w]) { stop_hint = iv[w] >> 16; break; }
+        }
         // 1. inflate (threads) and find the record boundaries up to the first alignment starting at or after end0
-        BlockStream bs(b, voff, b.io_threads, true);
+        BlockStream bs(b, voff, b.io_threads, true, stop_hint);
         std::vector<std::pair<size_t, size_t>> recs;    // (offset of the body in bs.data, size)
         for (;;) {
             size_t rn;
@@ -293,7 +305,7 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::
         // 2. parse them (threads), 3. filter and intern barcode / read ids in file order
         std::vector<Aln> parsed(recs.size());
         {
-            const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)b.io_threads, recs.size() / 256 + 1));
+            const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)b.io_threads, recs.size() / 2048 + 1));
             auto work = [&](int t) {
                 const size_t lo = recs.size() * (size_t)t / (size_t)T, hi = recs.size() * (size_t)(t + 1) / (size_t)T;
                 int32_t rt;

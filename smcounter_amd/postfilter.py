@@ -30,34 +30,58 @@ def load_repeat_regions(bed_target: str, bed_tandem: Optional[str], bed_repeatma
     return trf, rm
 
 
-def apply_repeat_filters(rows: List[str], trf, rm) -> List[str]:
-    """Append RepT / RepS / LowC / SL / Other_Repeat to the raw FILTER of rows with int(PI) >= 5 and
-    ALT != 'DEL', then turn ';' into PASS and strip the semicolons (smCounter.py:751-785).  Rows whose
-    POS or VMF is not numeric (the Zero_Coverage rows) pass through untouched, as in the reference."""
-    out = []
-    for row in rows:
-        f = row.split("\t")
-        try:
-            pos = int(f[_COL["POS"]])
-            vmf = float(f[_COL["VMF"]])
-        except ValueError:
-            out.append(row)
-            continue
-        try:
-            pred = int(float(f[_COL["PI"]]))
-        except ValueError:
-            pred = 0
-        if pred >= 5 and f[_COL["ALT"]] != "DEL":
-            chrom = f[_COL["CHROM"]]
-            if vmf < 40:          # sic: a fraction compared with 40, always true (:772)
-                for lo, hi, flag in trf.get(chrom, ()):
-                    if lo < pos <= hi:
-                        f[-1] += flag
-                        break
-            for lo, hi, flag in rm.get(chrom, ()):
+def _apply_one(row: str, trf, rm) -> str:
+    f = row.split("\t")
+    try:
+        pos = int(f[_COL["POS"]])
+        vmf = float(f[_COL["VMF"]])
+    except ValueError:
+        return row
+    try:
+        pred = int(float(f[_COL["PI"]]))
+    except ValueError:
+        pred = 0
+    if pred >= 5 and f[_COL["ALT"]] != "DEL":
+        chrom = f[_COL["CHROM"]]
+        if vmf < 40:          # sic: a fraction compared with 40, always true (:772)
+            for lo, hi, flag in trf.get(chrom, ()):
                 if lo < pos <= hi:
                     f[-1] += flag
                     break
-        f[-1] = "PASS" if f[-1] == ";" else f[-1].strip(";")
-        out.append("\t".join(f))
+        for lo, hi, flag in rm.get(chrom, ()):
+            if lo < pos <= hi:
+                f[-1] += flag
+                break
+    f[-1] = "PASS" if f[-1] == ";" else f[-1].strip(";")
+    return "\t".join(f)
+
+
+def apply_repeat_filters(rows: List[str], trf, rm) -> List[str]:
+    """Append RepT / RepS / LowC / SL / Other_Repeat to the raw FILTER of rows with int(PI) >= 5 and
+    ALT != 'DEL', then turn ';' into PASS and strip the semicolons (smCounter.py:751-785).  Rows whose
+    POS or VMF is not numeric (the Zero_Coverage rows) pass through untouched, as in the reference.
+    (`_apply_one` is the plain statement; the loop below does the same on the unchanged rows - nearly all of a
+    panel: PI below 5, FILTER ';' - without splitting all 45 fields.)"""
+    out = []
+    i_pi, i_vmf = _COL["PI"], _COL["VMF"]
+    assert i_pi < i_vmf and _COL["FILTER"] == len(HEADER_ALL) - 1
+    for row in rows:
+        if not row.endswith("\t;"):
+            out.append(_apply_one(row, trf, rm))
+            continue
+        head = row.split("\t", i_vmf + 1)
+        if len(head) != i_vmf + 2:
+            out.append(_apply_one(row, trf, rm))
+            continue
+        try:
+            int(head[_COL["POS"]])
+            float(head[i_vmf])
+            pred = int(float(head[i_pi]))
+        except ValueError:
+            out.append(_apply_one(row, trf, rm))
+            continue
+        if pred >= 5:
+            out.append(_apply_one(row, trf, rm))
+        else:
+            out.append(row[:-1] + "PASS")
     return out

@@ -69,15 +69,18 @@ def write_outputs(out_prefix: str, rows: List[str], threshold: int) -> None:
         f_all.write("\t".join(HEADER_ALL) + "\n")
         f_cut.write("\t".join(HEADER_VARIANTS) + "\n")
         f_vcf.write("\n".join(_VCF_META) + "\n" + sample_col + "\n")
+        if rows:
+            f_all.write("\n".join(rows) + "\n")
+        i_pi, i_alt = _COL["PI"], _COL["ALT"]
         for row in rows:
-            f_all.write(row + "\n")
+            f = row.split("\t", i_pi + 1)                    # (most rows stop here: PI below the threshold)
+            if not f[i_pi]:
+                continue                                     # Zero_Coverage rows
+            qual = str(int(float(f[i_pi])))                  # truncated, phred-like
+            if int(qual) < threshold or f[i_alt] == "DEL":
+                continue
             f = row.split("\t")
             g = {name: f[i] for name, i in _COL.items()}
-            if not g["PI"]:
-                continue                                     # Zero_Coverage rows
-            qual = str(int(float(g["PI"])))                  # truncated, phred-like
-            if int(qual) < threshold or g["ALT"] == "DEL":
-                continue
             thr = str(threshold)
             info = ";".join(k + "=" + v for k, v in (
                 ("TYPE", g["TYPE"]), ("DP", g["DP"]), ("MT", g["MT"]), ("UMT", g["UMT"]), ("PI", g["PI"]),

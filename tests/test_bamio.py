@@ -1,4 +1,5 @@
 """f2: BGZF/BAM reader and single-position pileup against a naive expansion of the same reads."""
+import os
 import numpy as np
 import pytest
 
@@ -255,6 +256,16 @@ def test_native_fused_planes_match_extract_features(tmp_path, max_reads, nthread
     assert [f for f, _ in want] == [f for f, _ in got]
     for (_, a), (_, b) in zip(want, got):
         _assert_device_batches_equal(a, b)
+    # a batch whose runs do not fit the shared arrays falls back to per-run arrays + concatenation: same batches
+    slack = bamio._ARENA_SLACK
+    try:
+        bamio._ARENA_SLACK = -max_reads // 2 if max_reads < 10**6 else 0
+        again = list(bamio.iter_device_batches_native(bam, fa, loci, P, max_reads=max_reads, nthreads=nthreads))
+    finally:
+        bamio._ARENA_SLACK = slack
+    assert len(again) == len(got)
+    for (_, a), (_, b) in zip(got, again):
+        _assert_device_batches_equal(a, b)
     flags = np.concatenate([b.meta for _, b in got]) >> 16 & 0xff
     assert len(set((flags >> 3).tolist())) == 4 and (flags & 4).any() and not (flags & 4).all()
     sampled = np.concatenate([b.loci["flags"] for _, b in got]) & features.LF_SAMPLED
@@ -310,3 +321,51 @@ def test_native_decoder_any_locus_order(tmp_path):
             for k in ("meta", "umi", "frag", "dist"):
                 assert np.array_equal(getattr(b, k)[o:o + n], getattr(dbw, k)[ow:ow + n]), k
         off += b.n_loci
+
+
+@pytest.mark.parametrize("nthreads", [1, 4])
+def test_native_decoder_many_blocks_several_index_windows(tmp_path, nthreads):
+    """A BAM of a few hundred BGZF blocks over five 16 kb index windows, read in many small runs: the decoder's
+    read-ahead bound (linear-index hint) and its streaming cursor never cost a read - same batches as the Python
+    decoder, in file order and for targets visited out of order."""
+    rng = np.random.RandomState(5)
+    L, RL = 80000, 100
+    seq = "".join(rng.choice(list("ACGT"), L))
+    fa_path = str(tmp_path / "w.fa")
+    with open(fa_path, "w") as fh:
+        fh.write(">chrW\n")
+        for i in range(0, L, 60):
+            fh.write(seq[i:i + 60] + "\n")
+    recs = []
+    for i in range(9000):
+        pos = int(rng.randint(100, L - 2 * RL))
+        cigar = [(0, RL)] if i % 50 else [(0, 40), (3, 20000 if pos < 30000 else 50), (0, 60)]    # a few long N skips
+        qual = rng.randint(20, 41, RL).astype(np.uint8).tolist()
+        recs.append(dict(tid=0, pos=pos, qname="m:%d:r%d:NN:%s:x" % (i % 7, i // 2, "ACGT"[i % 4] * 3 + "TG"[i % 2] * 2),
+                         flag=(0x41 if i % 2 == 0 else 0x91), mapq=60, cigar=cigar,
+                         seq=seq[pos:pos + RL], qual=qual, nm=i % 3))
+    recs.sort(key=lambda r: r["pos"])
+    bam = str(tmp_path / "w.bam")
+    bamio.write_bam(bam, [("chrW", L)], recs, block=6000)            # ~300 BGZF blocks
+    bamio.write_bai(bam)
+    fa = fasta.FastaFile(fa_path)
+    targets = [(150, 260), (16300, 16420), (16500, 16530), (33000, 33100), (49100, 49160), (65500, 65600), (77000, 77050)]
+    loci = [("chrW", str(p + 1)) for a, b in targets for p in range(a, b)]
+    shuffled = [("chrW", str(p + 1)) for a, b in [targets[i] for i in (3, 0, 6, 1, 5, 2, 4)] for p in range(a, b)]
+    P = VcParams(mismatchThr=4.0, mtDepth=1000)
+    assert os.path.getsize(bam) > 200 * 1000
+    for ll in (loci, shuffled):
+        py = pileup.concat([b for _, b in bamio.iter_pileup_batches(bamio.BamFile(bam), fa, ll, max_reads=900)])
+        nat = pileup.concat([b for _, b in bamio.iter_pileup_batches_native(bam, fa, ll, max_reads=900)])
+        assert py.n_reads > 3000
+        assert np.array_equal(py.pos, nat.pos) and np.array_equal(py.read_off, nat.read_off)
+        assert py.alleles == nat.alleles
+        for k, _ in bamio._COLS:
+            assert np.array_equal(getattr(py, k), getattr(nat, k)), k
+        # the fused path (threads inflate and parse)
+        want = [(f, features.extract_features(pb, P))
+                for f, pb in bamio.iter_pileup_batches(bamio.BamFile(bam), fa, ll, max_reads=900)]
+        got = list(bamio.iter_device_batches_native(bam, fa, ll, P, max_reads=900, nthreads=nthreads))
+        assert [f for f, _ in want] == [f for f, _ in got]
+        for (_, a), (_, b) in zip(want, got):
+            _assert_device_batches_equal(a, b)

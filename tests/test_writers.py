@@ -58,3 +58,34 @@ def test_repeat_post_filter(tmp_path):
          row(156, 4.99), row(156, 50.0, alt="DEL"), "chr1\t7\tA" + "\t" * 41 + "\tZero_Coverage"], t, r)
     last = [o.split("\t")[-1] for o in out]
     assert last == ["RepT", "PASS", "RepT", "LM;RepT;LowC;RepS", "Other_Repeat", "PASS", "PASS", "Zero_Coverage"]
+
+
+def test_post_filter_fast_path_equals_the_plain_statement(tmp_path):
+    """apply_repeat_filters' shortcut for unchanged rows against the row-by-row statement, on the reference's own
+    2000 example rows (FILTER turned back into the raw ';' form) and on malformed / short rows."""
+    rows = open(os.path.join(EX, "example.smCounter.all.txt")).read().split("\n")[1:-1]
+    raw = []
+    for r in rows:
+        f = r.split("\t")
+        if f[-1] != "Zero_Coverage":
+            f[-1] = ";" if f[-1] == "PASS" else ";" + f[-1] + ";"
+        raw.append("\t".join(f))
+    raw += ["chr1\t5\tA\t;", "x\t;", "chr1\tNaN\tA\tT\tSNP" + "\t1" * 39 + "\t;", "chr1\t9\tA\tT\tSNP\t1\t1\t1\t1\t1\tabc"
+            + "\t1" * 33 + "\t;", "chr1\t9\tA\tT\tSNP\t1\t1\t1\t1\t1\t7.5\t1\t1\t1\t" + "\t1" * 29 + "\t;"]
+    trf = {"chr1": [(0, 10**9, "RepT;")]}
+    rm = {"chr1": [(115250000, 115260000, "LowC;")]}
+    for t, r in (({}, {}), (trf, rm)):
+        want = []
+        for x in raw:
+            try:
+                want.append(postfilter._apply_one(x, t, r))
+            except Exception as e:                   # malformed rows fail the same way on both paths
+                want.append(type(e))
+        got = []
+        for x in raw:
+            try:
+                got.extend(postfilter.apply_repeat_filters([x], t, r))
+            except Exception as e:
+                got.append(type(e))
+        assert got == want
+    assert postfilter.apply_repeat_filters(raw[:2000], {}, {}) == rows
