@@ -19,20 +19,56 @@
 #include <atomic>
 #include <chrono>
 #include <string>
+#include <string_view>
 #include <thread>
 #include <unordered_map>
 #include <vector>
 
 namespace {
 
+const char SEQ_CODE[] = "=ACMGRSVTWYHKDBN";
+
+// Views into the inflated record bytes (kept in Bam::rec_data until the next run): an alignment owns no memory, so
+// parsing copies nothing and dropping a run's alignments frees nothing.
+struct CigView {                   // CIGAR words, len << 4 | op (not necessarily 4-byte aligned in the record)
+    const uint8_t* p = nullptr;
+    uint32_t n = 0;
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    uint32_t operator[](size_t k) const { uint32_t c; memcpy(&c, p + 4 * k, 4); return c; }
+    struct It {
+        const uint8_t* p;
+        uint32_t operator*() const { uint32_t c; memcpy(&c, p, 4); return c; }
+        It& operator++() { p += 4; return *this; }
+        bool operator!=(const It& o) const { return p != o.p; }
+    };
+    It begin() const { return It{p}; }
+    It end() const { return It{p + 4 * (size_t)n}; }
+};
+struct SeqView {                   // 4-bit packed bases, decoded on access
+    const uint8_t* p = nullptr;
+    uint32_t n = 0;
+    char operator[](size_t i) const { return SEQ_CODE[(p[i >> 1] >> ((i & 1) ? 0 : 4)) & 15]; }
+    std::string substr(size_t o, size_t len) const {
+        std::string r;
+        for (size_t i = o; i < n && i < o + len; ++i) r.push_back((*this)[i]);
+        return r;
+    }
+};
+struct QualView {
+    const uint8_t* p = nullptr;
+    uint8_t operator[](size_t i) const { return p[i]; }
+};
+
 struct Aln {
     int32_t pos, end;
     uint16_t flag;
     uint8_t mapq, has_nm;
     uint32_t nm, l_seq;
-    std::string qname, seq;
-    std::vector<uint8_t> qual;
-    std::vector<uint32_t> cigar;   // len << 4 | op
+    std::string_view qname;
+    SeqView seq;
+    QualView qual;
+    CigView cigar;
     int32_t bc_gid, pair_gid;      // run-wide ids of the barcode and of (barcode, read id)
     int32_t c1, c2;                // positions of the last two ':' of qname (-1: fewer than 3 fields)
     uint64_t h_bc, h_pair;         // hashes of the barcode and of the whole <readid>:<barcode> prefix
@@ -44,6 +80,7 @@ struct Bam {
     FILE* fh = nullptr;
     std::string err;
     int io_threads = 1;                // threads inflating BGZF blocks in collect_reads
+    std::vector<uint8_t> rec_data;     // inflated records of the last collect_reads (its alignments point into it)
     // streaming cursor: where the previous collect_reads found its first overlapping record - a later run on the
     // same reference that starts at or after the previous one never needs anything before it
     int cur_tid = -1;
@@ -111,8 +148,6 @@ struct Bam {
     }
 };
 
-const char SEQ_CODE[] = "=ACMGRSVTWYHKDBN";
-
 // one alignment record (without its block_size word) -> Aln
 void parse_body(const uint8_t* p, size_t r_size, Aln& a, int32_t& tid) {
     int32_t pos, l_seq;
@@ -124,15 +159,13 @@ void parse_body(const uint8_t* p, size_t r_size, Aln& a, int32_t& tid) {
     memcpy(&l_seq, p + 16, 4);
     a.pos = pos; a.l_seq = (uint32_t)l_seq;
     size_t o = 32;
-    a.qname.assign((const char*)p + o, l_name ? l_name - 1 : 0);
+    a.qname = std::string_view((const char*)p + o, l_name ? l_name - 1 : 0);
     o += l_name;
-    a.cigar.resize(n_cig);
-    memcpy(a.cigar.data(), p + o, 4 * n_cig);
+    a.cigar.p = p + o; a.cigar.n = n_cig;
     o += 4 * n_cig;
-    a.seq.resize((size_t)l_seq);
-    for (int i = 0; i < l_seq; ++i) a.seq[i] = SEQ_CODE[(p[o + (i >> 1)] >> ((i & 1) ? 0 : 4)) & 15];
+    a.seq.p = p + o; a.seq.n = (uint32_t)l_seq;
     o += (l_seq + 1) / 2;
-    a.qual.assign(p + o, p + o + l_seq);
+    a.qual.p = p + o;
     o += l_seq;
     a.nm = 0; a.has_nm = 0;
     while (o + 3 <= r_size) {   // aux: find NM (smCounter.py:329-334)
@@ -302,6 +335,9 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::
             if (rt < tid) continue;
             recs.emplace_back((size_t)(rp - bs.data.data()), rn);
         }
+        // (the alignments are views into the inflated bytes: those move into the handle and live until the next run)
+        b.rec_data = std::move(bs.data);
+        const uint8_t* const rec_base = b.rec_data.data();
         // 2. parse them (threads), 3. filter and intern barcode / read ids in file order
         std::vector<Aln> parsed(recs.size());
         {
@@ -311,7 +347,7 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::
                 int32_t rt;
                 for (size_t i = lo; i < hi; ++i) {
                     Aln& a = parsed[i];
-                    parse_body(bs.data.data() + recs[i].first, recs[i].second, a, rt);
+                    parse_body(rec_base + recs[i].first, recs[i].second, a, rt);
                     a.n_ind = 0; a.qalen = 0;
                     for (uint32_t c : a.cigar) {
                         const unsigned op = c & 15;
@@ -320,7 +356,7 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::
                     }
                     a.left_sp = (!a.cigar.empty() && (a.cigar[0] & 15) == 4) ? (a.cigar[0] >> 4) : 0u;
                     {
-                        const std::string& qn = a.qname;
+                        const std::string_view qn = a.qname;
                         const size_t c1 = qn.rfind(':');
                         const size_t c2 = (c1 == std::string::npos || c1 == 0) ? std::string::npos : qn.rfind(':', c1 - 1);
                         a.c1 = c1 == std::string::npos ? -1 : (int32_t)c1;
@@ -361,9 +397,9 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::
                 b.cur_end = end0; b.cur_voff_end = bs.voffset_of(recs[pi].first - 4);
             }
             // qname -> barcode / read id (smCounter.py:320-325): <readid...>:<UMI>:<x>
-            const std::string& qn = a.qname;
-            if (a.c2 < 0) { b.err = "read name '" + qn + "' has fewer than 3 ':' fields"; return -3; }
-            if (a.l_seq == 0) { b.err = "alignment " + qn + " has no sequence"; return -4; }
+            const std::string_view qn = a.qname;
+            if (a.c2 < 0) { b.err = "read name '" + std::string(qn) + "' has fewer than 3 ':' fields"; return -3; }
+            if (a.l_seq == 0) { b.err = "alignment " + std::string(qn) + " has no sequence"; return -4; }
             const size_t c1 = (size_t)a.c1, c2 = (size_t)a.c2;
             auto same_bc = [&](const Aln& o) {
                 return (size_t)(o.c1 - o.c2) == c1 - c2 && memcmp(o.qname.data() + o.c2 + 1, qn.data() + c2 + 1, c1 - c2 - 1) == 0;
@@ -371,9 +407,9 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::
             {
                 auto it = hb.find(a.h_bc);
                 if (it != hb.end() && same_bc(reads[bc_rep[(size_t)it->second]])) a.bc_gid = it->second;
-                else if (it == hb.end()) { a.bc_gid = (int)bc_rep.size(); hb.emplace(a.h_bc, a.bc_gid); bc_rep.push_back(reads.size()); bc_ids.emplace(qn.substr(c2 + 1, c1 - c2 - 1), a.bc_gid); }
+                else if (it == hb.end()) { a.bc_gid = (int)bc_rep.size(); hb.emplace(a.h_bc, a.bc_gid); bc_rep.push_back(reads.size()); bc_ids.emplace(std::string(qn.substr(c2 + 1, c1 - c2 - 1)), a.bc_gid); }
                 else {                                   // hash collision: fall back to the string map
-                    auto r = bc_ids.emplace(qn.substr(c2 + 1, c1 - c2 - 1), (int)bc_rep.size());
+                    auto r = bc_ids.emplace(std::string(qn.substr(c2 + 1, c1 - c2 - 1)), (int)bc_rep.size());
                     if (r.second) bc_rep.push_back(reads.size());
                     a.bc_gid = r.first->second;
                 }
@@ -387,7 +423,7 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::
                 if (hit) a.pair_gid = it->second;
                 else if (it == hp.end()) { a.pair_gid = (int)pair_rep.size(); hp.emplace(a.h_pair, a.pair_gid); pair_rep.push_back(reads.size()); }
                 else {
-                    auto r = pair_ids.emplace(qn.substr(c2 + 1, c1 - c2 - 1) + "\x01" + qn.substr(0, c2), (int)pair_rep.size());
+                    auto r = pair_ids.emplace(std::string(qn.substr(c2 + 1, c1 - c2 - 1)) + "\x01" + std::string(qn.substr(0, c2)), (int)pair_rep.size());
                     if (r.second) pair_rep.push_back(reads.size());
                     a.pair_gid = r.first->second;
                 }
@@ -688,7 +724,7 @@ int64_t smc_bam_planes(void* h, const char* chrom, int64_t start0, int64_t end0,
                 const int ai = allele_of(a, qpos, isdel, indel, extra);
                 if (ai >= SMC_MAX_ALLELES) { t_err[(size_t)t] = "more than 64 distinct alleles at " + std::string(chrom) + ":" + std::to_string(p0 + 1); err = -8; return; }
                 const unsigned bq = isdel ? 0u : a.qual[(size_t)qpos];
-                if (bq > 126) { t_err[(size_t)t] = "base quality " + std::to_string(bq) + " > 126 in " + a.qname; err = -7; return; }
+                if (bq > 126) { t_err[(size_t)t] = "base quality " + std::to_string(bq) + " > 126 in " + std::string(a.qname); err = -7; return; }
                 // pairOrder: R2 wins over R1; neither -> the previous read's value (smCounter.py:359-362)
                 if (a.oflag & 3) r2 = (a.oflag & 2) != 0;
                 else if (first) { t_err[(size_t)t] = "first pileup read at " + std::string(chrom) + ":" + std::to_string(p0 + 1) + " has neither read1 nor read2 set"; err = -6; return; }
