@@ -91,6 +91,12 @@ CONFIGS = {
     # scripts/quick_perf.py to watch the deep-locus launch classes (512 / 1024 threads, global tables)
     "X1": SynthConfig("X1", 2_000, 3600, 9, 20170420),
     "X2": SynthConfig("X2", 20_000, 600, 10, 20170421),
+    # shapes either side of the workgroup-size thresholds (on-chip tables per locus: ~17 / 30 / 42 / 51 KB)
+    "X6": SynthConfig("X6", 20_000, 100, 60, 20170425),
+    "X7": SynthConfig("X7", 15_000, 800, 10, 20170426),
+    "X4": SynthConfig("X4", 10_000, 1200, 10, 20170423),
+    "X5": SynthConfig("X5", 8_000, 1450, 10, 20170424),
+    "X8": SynthConfig("X8", 6_000, 2000, 10, 20170427),       # ~71 KB
     # C3's shape with a 10 % variant at 30 % of the loci: a third of the rows goes through k_filter_loci
     "X3": SynthConfig("X3", 40_000, 50, 60, 20170422, alt_locus_frac=0.3, alt_af=0.1),
 }
