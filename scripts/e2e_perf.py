@@ -81,3 +81,16 @@ for rep in range(2):
           "format rows %.2fs (%.0f loci/s) | post-filter+writers %.2fs | total %.2fs -> %.0f loci/s" % (
               rep, len(out), n_rd, t_dec, n_rd / t_dec / 1e6, t_gpu, t_fmt, len(out) / t_fmt, t6 - t5, t6 - t,
               len(out) / (t6 - t)))
+
+# the command line itself, as a child process (interpreter start, imports, context creation included)
+import subprocess
+eng.close()
+for rep in range(2):
+    t = time.time()
+    subprocess.check_call([sys.executable, "-m", "smcounter_amd.cli", "--outPrefix", os.path.join(tmp, "cli"), "--bamFile", bam,
+                           "--bedTarget", bed, "--mtDepth", str(P.mtDepth), "--rpb", str(P.rpb), "--refGenome", fa,
+                           "--logFile", os.path.join(tmp, "cli.log")], cwd=ROOT)
+    dt = time.time() - t
+    print("command line (child process), run %d: %.2f s wall for %d loci -> %.0f loci/s" % (rep, dt, len(loci), len(loci) / dt))
+same = open(os.path.join(tmp, "cli.smCounter.all.txt")).read() == open(os.path.join(tmp, "o.smCounter.all.txt")).read()
+print("its all.txt equals the in-process one:", same)

@@ -23,7 +23,9 @@ class SmcError(RuntimeError):
 _LIB = None
 
 
-def load():
+def load(with_torch: bool = True):
+    """dlopen + bind the C ABI.  `with_torch=False` skips importing PyTorch first (about a second of start-up): only
+    for processes that will never import it afterwards - the single-process command line."""
     global _LIB
     if _LIB is not None:
         return _LIB
@@ -32,10 +34,11 @@ def load():
                        "(or python -m smcounter_amd.build); there is no CPU fallback" % LIB_PATH)
     # PyTorch-ROCm ships its own HIP runtime; it must be the first one mapped into the process, or
     # torch later finds "No HIP GPUs" behind the system libamdhip64 this library would pull in.
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    if with_torch:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = ctypes.CDLL(LIB_PATH)
     vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
     L.smc_abi_version.restype = ctypes.c_int

@@ -118,6 +118,11 @@ def main(args) -> int:
     # ordered locus list (loci share nothing, smCounter.py:683-685) on GPU LOCAL_RANK, rank 0 gathers the rows
     # in submission order and writes the files.
     rank, local_rank, world = smcdist.init_from_env()
+    if world == 1:
+        # a single process never touches torch.distributed: bind the C ABI without importing PyTorch first
+        # (about a second of start-up; the host-buffer entry point needs none of it)
+        from . import _lib
+        _lib.load(with_torch=False)
     lo, hi = smcdist.shard_range(len(loc_list), rank, world)
     output = call_shard(args, params, loc_list[lo:hi], local_rank if world > 1 else args.device)
     vc.raise_on_exception(output, loc_list[lo:hi])
