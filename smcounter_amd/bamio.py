@@ -235,6 +235,32 @@ def _load_bai(path: str, n_ref: int):
     return lin
 
 
+def locus_weights(path: str, loci: Sequence[Tuple[str, str]]) -> np.ndarray:
+    """A depth proxy per locus for balancing shards without decoding anything: compressed bytes of the locus's 16 kb
+    window according to the BAI linear index (file offsets of the first alignment of every window).  Panels put one
+    amplicon in a window, so this is proportional to the amplicon's reads.  All ones when there is no index."""
+    w = np.ones(len(loci), np.float64)
+    try:
+        bam = BamFile(path)
+    except (OSError, BamError):
+        return w
+    lin, tid_of = bam._lin_index, bam.tid_of
+    bam.close()
+    if not lin:
+        return w
+    size = os.path.getsize(path)
+    starts = [(tid, k, v >> 16) for tid, iv in enumerate(lin) for k, v in enumerate(iv) if v]
+    dens = {}
+    for j, (tid, k, c) in enumerate(starts):
+        nxt = starts[j + 1][2] if j + 1 < len(starts) else size
+        dens[(tid, k)] = float(max(nxt - c, 0))
+    for i, (chrom, pos) in enumerate(loci):
+        tid = tid_of.get(chrom)
+        if tid is not None:
+            w[i] = 1.0 + dens.get((tid, (int(pos) - 1) >> 14), 0.0)
+    return w
+
+
 def write_bam(path: str, refs: Sequence[Tuple[str, int]], records: Iterable[dict], block: int = 60000) -> None:
     """Tiny BAM writer (coordinate-sorted input expected).  record keys: tid, pos, qname, flag, mapq,
     cigar [(op, len)], seq, qual (bytes or list of ints), nm (int or None)."""

@@ -123,7 +123,14 @@ def main(args) -> int:
         # (about a second of start-up; the host-buffer entry point needs none of it)
         from . import _lib
         _lib.load(with_torch=False)
-    lo, hi = smcdist.shard_range(len(loc_list), rank, world)
+    if world > 1:
+        # contiguous ranges balanced by depth, not by locus count (amplicon depth varies several-fold): the BAI's
+        # linear index gives compressed bytes per 16 kb window without decoding anything; every rank computes the
+        # same cuts
+        cuts = smcdist.shard_by_reads(bamio.locus_weights(args.bamFile, loc_list), world)
+        lo, hi = cuts[rank], cuts[rank + 1]
+    else:
+        lo, hi = 0, len(loc_list)
     output = call_shard(args, params, loc_list[lo:hi], local_rank if world > 1 else args.device)
     vc.raise_on_exception(output, loc_list[lo:hi])
     if world > 1:

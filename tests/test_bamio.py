@@ -369,3 +369,32 @@ def test_native_decoder_many_blocks_several_index_windows(tmp_path, nthreads):
         assert [f for f, _ in want] == [f for f, _ in got]
         for (_, a), (_, b) in zip(want, got):
             _assert_device_batches_equal(a, b)
+
+
+def test_locus_weights_follow_depth_and_balance_the_shards(tmp_path):
+    """Two amplicons, the second eight times deeper: the BAI-derived weights put most of the first amplicon's loci
+    and few of the second's into rank 0, the read counts of the two halves come out close."""
+    from smcounter_amd import dist
+    rng = np.random.RandomState(3)
+    L, RL = 60000, 100
+    seq = "".join(rng.choice(list("ACGT"), L))
+    recs = []
+    for start, n in ((1000, 300), (40000, 2400)):
+        for i in range(n):
+            pos = start + int(rng.randint(0, 60))
+            recs.append(dict(tid=0, pos=pos, qname="m:1:r%d_%d:NN:%s:x" % (start, i // 2, "ACGT"[i % 4] * 4),
+                             flag=(0x41 if i % 2 == 0 else 0x91), mapq=60, cigar=[(0, RL)], seq=seq[pos:pos + RL],
+                             qual=[30] * RL, nm=0))
+    recs.sort(key=lambda r: r["pos"])
+    bam = str(tmp_path / "d.bam")
+    bamio.write_bam(bam, [("chrD", L)], recs, block=8000)
+    bamio.write_bai(bam)
+    loci = [("chrD", str(p + 1)) for a in (1000, 40000) for p in range(a + 20, a + 120)]
+    w = bamio.locus_weights(bam, loci)
+    assert w[:100].std() == 0 and w[100:].std() == 0 and 4 < w[150] / w[50] < 16
+    cuts = dist.shard_by_reads(w, 2)
+    assert cuts[0] == 0 and cuts[2] == 200 and 100 < cuts[1] < 160
+    depth = np.array([sum(1 for r in recs if r["pos"] <= int(p) - 1 < r["pos"] + RL) for _, p in loci])
+    halves = depth[:cuts[1]].sum(), depth[cuts[1]:].sum()
+    assert 0.6 < halves[0] / halves[1] < 1.6                       # (by locus count it would be 1 : 8)
+    assert (bamio.locus_weights(str(tmp_path / "missing.bam"), loci) == 1).all()
