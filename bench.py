@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--loci-per-gpu", type=int, default=0, help="override (default: the config's size)")
     ap.add_argument("--chunk", type=int, default=25000, help="loci generated/uploaded per chunk")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rows", choices=("gather", "resident"), default="gather",
+                    help="N > 1: gather every step's rows to rank 0 (default; overlapped with the next step) or leave "
+                         "them in each rank's HBM (diagnostic: isolates the collective)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -100,7 +103,8 @@ def main():
 
     # N > 1: the rows of step i travel to rank 0 (RCCL, its own stream) while step i + 1 computes - two row
     # buffers per rank, a buffer is reused only after its gather has completed (dist.RowPipeline)
-    pipe = smcdist.RowPipeline([rows, plan.alloc_rows()] if use_dist else [rows], collective=use_dist)
+    gather = use_dist and a.rows == "gather"
+    pipe = smcdist.RowPipeline([rows, plan.alloc_rows()] if gather else [rows], collective=gather)
 
     def step():
         pipe.step(lambda buf: plan.run(planes, params, buf))
@@ -152,7 +156,8 @@ def main():
             "vs_baseline": None, "dtype": "u8/u32 scan + f64 posterior", "data": "synthetic",
             "config": {"workload": "%s: %d loci/GPU x %d reads (%d UMIs x %d rpb), seed %d"
                        % (cfg.name, n_loc, cfg.depth, cfg.n_umi, cfg.rpb, cfg.seed),
-                       "loci_total": total_loci, "parallelism": "loci sharded x%d, rows gathered to rank 0" % world,
+                       "loci_total": total_loci, "parallelism": "loci sharded x%d, %s" % (world, "rows gathered to rank 0" if (gather or world == 1) else
+                                                                  "rows left in each rank's HBM (--rows resident)"),
                        "build_s": round(t_build, 1)},
             "roofline": {"bound": "hbm", "kernel": "k_call_loci", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

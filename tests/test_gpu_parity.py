@@ -34,7 +34,10 @@ def test_golden_rows_vs_oracle_and_reference(engine0, path):
             assert d <= PI_TOL
 
 
-@pytest.mark.parametrize("name,n", [("C2", 3000), ("C3", 1500), ("C5", 300)])
+# C2 / C3 / X6 / X4 / X5 / X1: one shape per workgroup-size class of the launch plan (64 / 128 / 256 / 512 / 512 /
+# 1024 threads, host_abi.inc), C5 and X2 sit right above the 128 -> 256 threshold
+@pytest.mark.parametrize("name,n", [("C2", 3000), ("C3", 1500), ("C5", 300), ("X6", 300), ("X2", 200), ("X4", 100),
+                                    ("X5", 80), ("X1", 40)])
 def test_synthetic_configs_vs_oracle(engine0, name, n):
     cfg = synth.CONFIGS[name]
     P = synth.params_for(cfg)
