@@ -83,6 +83,19 @@ def test_huge_locus_uses_global_tables(engine0):
     assert abi.compare_rows(got, want, PI_TOL, P_TOL, fragile) == []
 
 
+def test_locus_above_2_to_18_reads(engine0):
+    """312,000 reads on one locus (the table kernel takes up to 2^24; pysam's max_depth in the reference is 10^6):
+    tables in the global scratch slab, rows equal to the CPU restatement."""
+    cfg = synth.SynthConfig("deep", 2, 5200, 60, 777)
+    P = synth.params_for(cfg)
+    db = synth.generate_native(cfg, 0, 2, P)
+    assert int(db.loci["n_reads"].min()) > (1 << 18)
+    got = engine0.call_batch_host(db, P)
+    want, fragile = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE, return_fragile=True)
+    assert abi.compare_rows(got, want, PI_TOL, P_TOL, fragile) == []
+    assert (got["cvg"] == 312000).all() and (got["used_mt"] == 5200).all()
+
+
 def test_long_scan_and_giant_barcode(engine0):
     """(a) a 128-thread locus scanned in more than 7 steps: the packed 5-bit tally accumulators are spilled on the
     way; (b) a barcode with more fragments than the per-count posterior table holds (>= 4096): scored by the general
