@@ -97,6 +97,9 @@ CONFIGS = {
     "X4": SynthConfig("X4", 10_000, 1200, 10, 20170423),
     "X5": SynthConfig("X5", 8_000, 1450, 10, 20170424),
     "X8": SynthConfig("X8", 6_000, 2000, 10, 20170427),       # ~71 KB
+    # the depth of the reference's own example run (58 k reads, ~7 k barcodes): beyond the LDS -> global-table path
+    "X9": SynthConfig("X9", 1_000, 6500, 9, 20170428),
+    "X10": SynthConfig("X10", 300, 20000, 9, 20170429),       # 180 k reads per locus
     # C3's shape with a 10 % variant at 30 % of the loci: a third of the rows goes through k_filter_loci
     "X3": SynthConfig("X3", 40_000, 50, 60, 20170422, alt_locus_frac=0.3, alt_af=0.1),
 }

@@ -83,6 +83,66 @@ def test_huge_locus_uses_global_tables(engine0):
     assert abi.compare_rows(got, want, PI_TOL, P_TOL, fragile) == []
 
 
+def test_segment_kernel_and_its_fallbacks(monkeypatch):
+    """Loci beyond the LDS go through k_call_segments (whole barcodes, a fixed LDS budget per segment), and come back
+    to the global-table launch when it cannot take them.  (a) the same batch with and without the segment kernel
+    (SMC_NO_SEGMENTS is read when the plan is made): identical rows, equal to the CPU restatement; (b) one barcode
+    larger than a segment; (c) more barcodes than the cap without the host's sampling marks (the whole-locus stand-in);
+    (d) a contract violation inside a later segment; (e) host sampling marks across segments."""
+    import dataclasses
+    from smcounter_amd import engine
+    cfg = synth.SynthConfig("big", 3, 7000, 12, 99)
+    P = synth.params_for(cfg)
+    db = synth.generate_native(cfg, 0, 3, P)
+    assert 4 * int(db.loci["n_frag"][0]) > 160 * 1024
+    want, fragile = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE, return_fragile=True)
+    eng = engine.Engine(0)
+    seg = eng.call_batch_host(db, P)
+    monkeypatch.setenv("SMC_NO_SEGMENTS", "1")
+    glob = eng.call_batch_host(db, P)
+    monkeypatch.delenv("SMC_NO_SEGMENTS")
+    assert abi.compare_rows(seg, want, PI_TOL, P_TOL, fragile) == []
+    assert seg.tobytes() == glob.tobytes()                       # order-independent sums: bit-identical rows
+    # (b) 5 barcodes x 12,400 reads: ~8,600 fragment slots each, more than a segment holds (8,192).  (Not deeper: from
+    # ~6,700 unpaired fragments in ONE barcode on, the likelihood products of calProb leave the double range and what
+    # is left depends on the multiplication order - sequential in the reference, a tree here; no real barcode is near.)
+    cfg_b = synth.SynthConfig("giant2", 2, 5, 12400, 4322)
+    Pb = synth.params_for(cfg_b)
+    dbb = synth.generate_native(cfg_b, 0, 2, Pb)
+    assert 4 * int(dbb.loci["n_frag"][0]) > 160 * 1024 and int(dbb.loci["n_frag"][0]) // 5 > 8192 + 200
+    got = eng.call_batch_host(dbb, Pb)
+    wb, fb = oracle_lib.call_batch(dbb, abi.c_params(Pb), abi.ROW_DTYPE, return_fragile=True)
+    assert abi.compare_rows(got, wb, PI_TOL, P_TOL, fb) == []
+    # (c) ds = 2 * mtDepth below the barcode count, no marks
+    Pc = dataclasses.replace(P, mtDepth=1000)
+    got = eng.call_batch_host(db, Pc)
+    wc = oracle_lib.call_batch(db, abi.c_params(Pc), abi.ROW_DTYPE)
+    assert (got["status"] & abi.ST_DOWNSAMPLED).all() and (got["used_mt"] == 2000).all()
+    assert abi.compare_rows(got, wc, PI_TOL, P_TOL) == []
+    # (d) a fragment slot out of range in the last third of locus 1: that row is flagged, the others are untouched
+    bad = dataclasses.replace(db, frag=db.frag.copy())
+    o = 4 * int(db.loci["read_off4"][1]) + int(db.loci["n_reads"][1]) * 5 // 6
+    bad.frag[o] = (bad.frag[o] & ~np.uint32(features.FRAG_SLOT_MASK)) | np.uint32(int(db.loci["n_frag"][1]) + 7)
+    got = eng.call_batch_host(bad, P)
+    assert got["status"][1] & abi.ST_BAD_INPUT
+    assert got[[0, 2]].tobytes() == seg[[0, 2]].tobytes()
+    # (e) marks: drop every third barcode of locus 0 down to exactly ds
+    Pe = dataclasses.replace(P, mtDepth=2500)                   # ds = 5000 < 7000
+    us = db.umi_start.copy()
+    o, nu = int(db.loci["umi_off"][0]), int(db.loci["n_umi"][0])
+    drop = np.arange(nu)[::3][:nu - 5000]
+    us[o + drop] |= np.uint32(features.USTART_DROPPED)
+    loci = db.loci.copy()
+    loci["flags"][0] |= features.LF_SAMPLED
+    dbe = dataclasses.replace(db, umi_start=us, loci=loci)
+    dbe = dataclasses.replace(dbe, loci=dbe.loci[:1].copy())     # (only the marked locus: the others would need marks too)
+    got = eng.call_batch_host(dbe, Pe)
+    we, fe = oracle_lib.call_batch(dbe, abi.c_params(Pe), abi.ROW_DTYPE, return_fragile=True)
+    assert int(got["used_mt"][0]) == 5000 and not (got["status"][0] & abi.ST_BAD_INPUT)
+    assert abi.compare_rows(got, we, PI_TOL, P_TOL, fe) == []
+    eng.close()
+
+
 def test_locus_above_2_to_18_reads(engine0):
     """312,000 reads on one locus (the table kernel takes up to 2^24; pysam's max_depth in the reference is 10^6):
     tables in the global scratch slab, rows equal to the CPU restatement."""
