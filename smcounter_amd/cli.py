@@ -62,7 +62,10 @@ def call_shard(args, params: VcParams, loci, device: int):
     if os.environ.get("SMC_BAM_DECODER", "native") == "python":       # readable decoder, same batches
         batches = bamio.iter_pileup_batches(bamio.BamFile(args.bamFile), ref, loci, max_reads=args.batchReads)
     else:
-        batches = bamio.iter_device_batches_native(args.bamFile, ref, loci, params, max_reads=args.batchReads)
+        # (one process per GPU: the ranks of a node share its cores for decoding)
+        nthreads = max(1, len(os.sched_getaffinity(0)) // max(1, int(os.environ.get("WORLD_SIZE", "1"))))
+        batches = bamio.iter_device_batches_native(args.bamFile, ref, loci, params, max_reads=args.batchReads,
+                                                   nthreads=nthreads)
     for first, pb in _prefetch(batches):
         output.extend(vc.vc_batch(pb, params, ref, eng=eng))
     eng.close()
