@@ -71,7 +71,8 @@ def test_stress_mix_of_sizes_and_bins(engine0):
 
 
 def test_huge_locus_uses_global_tables(engine0):
-    """Loci too large for LDS tables (> 160 KB): the global-scratch bin (checked through the plan's scratch size)."""
+    """Loci too large for LDS tables (> 160 KB): taken by k_call_segments, with the global-scratch bin behind it as the
+    hand-back (its slab shows in the plan's scratch size; test_segment_kernel_and_its_fallbacks runs that bin alone)."""
     cfg = synth.SynthConfig("big", 2, 7000, 12, 99)
     P = synth.params_for(cfg)
     db = synth.generate_native(cfg, 0, 2, P)
