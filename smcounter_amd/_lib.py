@@ -30,8 +30,14 @@ def load(with_torch: bool = True):
     if _LIB is not None:
         return _LIB
     if not os.path.exists(LIB_PATH):
-        raise SmcError("HIP library missing: %s - run `python -c 'import __graft_entry__ as g; g.build()'` "
-                       "(or python -m smcounter_amd.build); there is no CPU fallback" % LIB_PATH)
+        # not built yet in this tree: build it now (hipcc, about two minutes); without hipcc this fails loudly -
+        # there is no CPU fallback
+        try:
+            from . import build
+            build.build_hip()
+        except Exception as e:
+            raise SmcError("HIP library missing: %s and it could not be built (%s) - run `python -c 'import "
+                           "__graft_entry__ as g; g.build()'`; there is no CPU fallback" % (LIB_PATH, e))
     # PyTorch-ROCm ships its own HIP runtime; it must be the first one mapped into the process, or
     # torch later finds "No HIP GPUs" behind the system libamdhip64 this library would pull in.
     if with_torch:
