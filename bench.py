@@ -5,14 +5,22 @@ Metric (BASELINE.json): loci/s at fixed read-depth x reads-per-UMI.  Workload at
 BASELINE.json configs[2] "synthetic 200k loci, 3000x depth, 50 UMIs/locus, 60 rpb" PER GPU (weak
 scaling: rank r calls loci [r*200k, (r+1)*200k) of the same seeded config), inputs resident in HBM
 before the timed region.  A step = one pass of the hot path (k_call_loci bins + k_filter_loci) over
-the rank's batch, followed, for N > 1, by the gather of the fixed-width rows to rank 0 (RCCL; the gather of a
-step overlaps the next step's kernels, two row buffers per rank - every step's rows are gathered inside the timed
-region).
+the rank's batch, followed, for N > 1, by the gather of the rows to rank 0 (RCCL; the gather of a step
+overlaps the next step's kernels, two row buffers per rank - every step's rows are gathered inside the
+timed region).
+
+The timed region is a block of EXACTLY --steps steps between barrier + synchronize on both sides; the
+block is repeated --blocks times (default 5) and `value` / `ms_per_step` come from the MEDIAN block
+(every block's ms_per_step is listed under `blocks`): one 20-step block is ~30 ms, too short to trust
+to a percent.
 
 Prints ONE JSON line on rank 0 (see the task contract): value = loci of all ranks / max-over-ranks
 time; roofline = algorithmic bytes (16 B/read + 360 B/locus) of the dominant kernel
-over its mean HIP-event duration, against 8 TB/s; cpu_baseline = the C restatement under oracle/
-timed on one host core on a bounded sample of the same workload (rank 0, N = 1 only).
+over its mean HIP-event duration, against 8 TB/s, next to the bytes the kernel actually has to move
+(`needed_bytes_per_launch`, `frac_needed`); cpu_baseline = CPU legs timed on a bounded sample of the
+same workload (rank 0, N = 1 only); parity = EVERY row of the run against the CPU restatement with the
+number of loci whose order-dependent fields were excused; other_configs = the other single-GPU
+BASELINE configs (C2, C5), each timed the same way in the same process.
 """
 from __future__ import annotations
 
@@ -29,6 +37,99 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def needed_bytes(loci) -> float:
+    """HBM bytes one launch of the hot path has to move for these loci: the two planes the kernels read
+    (meta, frag: 8 B per read slot), umi_start, the 32-byte descriptor + 4-byte launch-order entry, and the row written."""
+    import numpy as np
+    from smcounter_amd import abi
+    slots = ((loci["n_reads"].astype(np.int64) + 3) // 4 * 4).sum()
+    return float(8 * slots + 4 * (loci["n_umi"].astype(np.int64) + 1).sum() + (32 + 4 + abi.ROW_DTYPE.itemsize) * len(loci))
+
+
+class Resident(object):
+    """One config's batch resident in HBM: the planes the kernels read + the plan; optionally the CPU restatement's rows
+    of every chunk (all host cores), kept for the parity pass."""
+
+    def __init__(self, eng, cfg, params, lo, hi, chunk, nthreads, dev, oracle=None):
+        import numpy as np
+        import torch
+        from smcounter_amd import abi, synth
+        n_loc = hi - lo
+        stride = (cfg.depth + 3) // 4 * 4
+        self.meta = torch.empty(n_loc * stride, dtype=torch.int32, device=dev)
+        self.frag = torch.empty(n_loc * stride, dtype=torch.int32, device=dev)
+        self.umi_start = torch.empty(n_loc * (cfg.n_umi + 1), dtype=torch.int32, device=dev)
+        loci_parts, self.want = [], []
+        for c0 in range(lo, hi, chunk):
+            c1 = min(hi, c0 + chunk)
+            db = synth.generate_native(cfg, c0, c1, params, nthreads=nthreads)
+            off = (c0 - lo) * stride
+            # (the umi and dist planes hold the raw fields the CPU restatement reads; the kernels do not: smcounter_hip.h)
+            self.meta[off:off + db.n_slots].copy_(torch.from_numpy(db.meta.view(np.int32)))
+            self.frag[off:off + db.n_slots].copy_(torch.from_numpy(db.frag.view(np.int32)))
+            uoff = (c0 - lo) * (cfg.n_umi + 1)
+            self.umi_start[uoff:uoff + len(db.umi_start)].copy_(torch.from_numpy(db.umi_start.view(np.int32)))
+            if oracle is not None:
+                self.want.append(oracle.call_batch_mt(db, abi.c_params(params), abi.ROW_DTYPE, nthreads, return_fragile=True,
+                                                      return_pi_all=True))
+            loc = db.loci.copy()
+            loc["read_off4"] += off // 4
+            loc["umi_off"] += uoff
+            loci_parts.append(loc)
+        self.loci = np.concatenate(loci_parts)
+        self.plan = eng.make_plan(self.loci)
+        self.planes = [self.meta, self.meta, self.frag, self.meta, self.umi_start]   # umi / dist slots: never dereferenced
+        self.params = params
+
+    def run(self, rows):
+        return self.plan.run(self.planes, self.params, rows)
+
+    def parity(self, rows):
+        import numpy as np
+        from smcounter_amd import abi
+        got = self.plan.download(rows)
+        tot = {"loci": 0, "mismatches": 0, "fragile_skipped": 0, "near_tie_skipped": 0, "pi_max_abs_diff": 0.0, "detail": []}
+        lo = 0
+        for want, fragile, pi_all in self.want:
+            rep = abi.parity_report(got[lo:lo + len(want)], want, fragile, pi_all)
+            for k in ("loci", "mismatches", "fragile_skipped", "near_tie_skipped"):
+                tot[k] += rep[k]
+            tot["pi_max_abs_diff"] = max(tot["pi_max_abs_diff"], rep["pi_max_abs_diff"])
+            tot["detail"] += rep["detail"]
+            lo += len(want)
+        tot["detail"] = tot["detail"][:3]
+        tot["checked_against"] = "oracle/smc_oracle.c on all host cores, every locus of the run"
+        return tot
+
+    def close(self):
+        self.plan.close()
+        self.meta = self.frag = self.umi_start = self.planes = None
+
+
+def roofline_block(plan_loci, k_ms, k_n, k_loci, k_reads, cfg_key):
+    alg_bytes = 16.0 * k_reads + 360.0 * k_loci              # per launch of the dominant kernel (SURVEY 8d)
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    need = needed_bytes(plan_loci)
+    # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), expressed like `achieved`:
+    # GB/s over THIS run's measured kernel duration.  A constant read from the committed profile, not measured here.
+    traffic, traffic_bytes, src = None, None, None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        rec = json.load(open(tpath)).get(cfg_key)
+        if rec:
+            traffic_bytes = rec["hbm_bytes_per_launch"]
+            traffic = traffic_bytes / (k_ms * 1e-3) / 1e9
+            src = "profiles/traffic.json <- " + rec.get("source", "rocprofv3 --pmc")
+    return {"bound": "hbm", "kernel": "k_call_loci", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+            "kernel_ms": k_ms, "kernel_samples": k_n, "loci_per_launch": k_loci,
+            "alg_bytes_per_launch": alg_bytes, "needed_bytes_per_launch": need,
+            "achieved_needed": need / (k_ms * 1e-3) / 1e9, "frac_needed": need / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "hbm_bytes_per_launch_pmc": traffic_bytes,
+            "note": "frac = SURVEY 8d's 16 B/read; the kernels load 8 B/read (meta + frag planes), so frac_needed is the "
+                    "fraction of the HBM peak actually required of the memory system"}
+
+
 def main():
     global np, torch, dist, abi, engine, synth, smcdist
     import numpy as np
@@ -37,13 +138,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps each; value = the median block")
     ap.add_argument("--config", default="C3", help="synthetic config (C2, C3, C5); C3 is the metric's")
     ap.add_argument("--loci-per-gpu", type=int, default=0, help="override (default: the config's size)")
     ap.add_argument("--chunk", type=int, default=25000, help="loci generated/uploaded per chunk")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the every-row check against the CPU restatement")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the C2 / C5 one-liners")
     ap.add_argument("--rows", choices=("gather", "resident"), default="gather",
                     help="N > 1: gather every step's rows to rank 0 (default; overlapped with the next step) or leave "
                          "them in each rank's HBM (diagnostic: isolates the collective)")
+    ap.add_argument("--wire", choices=("packed", "full"), default="packed",
+                    help="N > 1: what travels to rank 0 - the packed wire rows (default) or the full 432-byte rows")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -73,116 +179,151 @@ def main():
     lo, hi = smcdist.shard_range(n_loc * world, rank, world)      # contiguous, equal (weak scaling)
     eng = engine.Engine(local_rank)
     dev = torch.device("cuda", local_rank)
+    oracle = None
+    if world == 1 and not a.no_parity:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_lib as oracle
 
     # ---- build the rank's batch in HBM, chunk by chunk (host RAM stays bounded)
     t0 = time.time()
-    stride = (cfg.depth + 3) // 4 * 4
-    planes = [torch.empty(n_loc * stride, dtype=torch.int32, device=dev) for _ in range(4)]
-    planes.append(torch.empty(n_loc * (cfg.n_umi + 1), dtype=torch.int32, device=dev))      # umi_start
-    loci_parts, sample = [], None
-    nthreads = max(1, (os.cpu_count() or 1) // max(1, world))
-    for c0 in range(lo, hi, a.chunk):
-        c1 = min(hi, c0 + a.chunk)
-        db = synth.generate_native(cfg, c0, c1, params, nthreads=nthreads)
-        off = (c0 - lo) * stride
-        for pl, src in zip(planes, (db.meta, db.umi, db.frag, db.dist)):
-            pl[off:off + db.n_slots].copy_(torch.from_numpy(src.view(np.int32)))
-        uoff = (c0 - lo) * (cfg.n_umi + 1)
-        planes[4][uoff:uoff + len(db.umi_start)].copy_(torch.from_numpy(db.umi_start.view(np.int32)))
-        loc = db.loci.copy()
-        loc["read_off4"] += off // 4
-        loc["umi_off"] += uoff
-        loci_parts.append(loc)
-        if sample is None:
-            sample = db
-    loci = np.concatenate(loci_parts)
-    plan = eng.make_plan(loci)
+    nthreads = max(1, len(os.sched_getaffinity(0)) // max(1, world))
+    res = Resident(eng, cfg, params, lo, hi, a.chunk, nthreads, dev, oracle)
+    plan = res.plan
     rows = plan.alloc_rows()
     torch.cuda.synchronize()
     t_build = time.time() - t0
 
-    # N > 1: the rows of step i travel to rank 0 (RCCL, its own stream) while step i + 1 computes - two row
-    # buffers per rank, a buffer is reused only after its gather has completed (dist.RowPipeline)
+    # N > 1: the rows of step i travel to rank 0 (RCCL, its own stream) while step i + 1 computes - two buffers per rank,
+    # a buffer is reused only after its gather has completed (dist.RowPipeline).  What travels is the packed wire row
+    # (smc_pack_rows: every printed column, a third of the bytes) unless --wire full.
     gather = use_dist and a.rows == "gather"
-    pipe = smcdist.RowPipeline([rows, plan.alloc_rows()] if gather else [rows], collective=gather)
+    packed = gather and a.wire == "packed"
+    if packed:
+        wires = [plan.alloc_wire(), plan.alloc_wire()]
+
+        def produce(buf):
+            res.run(rows)
+            plan.pack(rows, buf)
+        pipe = smcdist.RowPipeline(wires, collective=True)
+    else:
+        def produce(buf):
+            res.run(buf)
+        pipe = smcdist.RowPipeline([rows, plan.alloc_rows()] if gather else [rows], collective=gather)
 
     def step():
-        pipe.step(lambda buf: plan.run(planes, params, buf))
-
-    drain = pipe.drain
+        pipe.step(produce)
 
     for _ in range(a.warmup):
         step()
-    drain()
+    pipe.drain()
     torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    plan.set_timing(min(a.steps, 64))
-    torch.cuda.synchronize()
-    t_start = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    drain()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t_start
+    blocks = []
+    plan.set_timing(min(a.steps * a.blocks, 256))
+    for _ in range(max(1, a.blocks)):
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        t_start = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        pipe.drain()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        elapsed = time.perf_counter() - t_start
+        if use_dist:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        blocks.append(elapsed)
     k_ms, k_n, k_loci, k_reads = plan.kernel_ms()
     plan.set_timing(0)
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sorted(blocks)[len(blocks) // 2]                   # the median block
 
     out = None
     if rank == 0:
         total_loci = n_loc * world
-        ms_per_step = elapsed / a.steps * 1e3
-        alg_bytes = 16.0 * k_reads + 360.0 * k_loci              # per launch of the dominant kernel
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), expressed
-        # like `achieved`: GB/s over this run's measured kernel duration
-        traffic, traffic_bytes = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            rec = json.load(open(tpath)).get("%s:%d" % (a.config, n_loc))
-            if rec:
-                traffic_bytes = rec["hbm_bytes_per_launch"]
-                traffic = traffic_bytes / (k_ms * 1e-3) / 1e9
         out = {
             "metric": "loci/sec at fixed read-depth x rpb", "value": total_loci * a.steps / elapsed,
             "unit": "loci/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/u32 scan + f64 posterior", "data": "synthetic",
             "config": {"workload": "%s: %d loci/GPU x %d reads (%d UMIs x %d rpb), seed %d"
                        % (cfg.name, n_loc, cfg.depth, cfg.n_umi, cfg.rpb, cfg.seed),
-                       "loci_total": total_loci, "parallelism": "loci sharded x%d, %s" % (world, "rows gathered to rank 0" if (gather or world == 1) else
-                                                                  "rows left in each rank's HBM (--rows resident)"),
+                       "loci_total": total_loci,
+                       "parallelism": "loci sharded x%d, %s" % (world, ("%s rows gathered to rank 0" % ("packed wire" if packed else "full"))
+                                                                 if gather else ("single GPU" if world == 1 else
+                                                                                 "rows left in each rank's HBM (--rows resident)")),
                        "build_s": round(t_build, 1)},
-            "roofline": {"bound": "hbm", "kernel": "k_call_loci", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel_ms": k_ms, "kernel_samples": k_n, "loci_per_launch": k_loci,
-                         "alg_bytes_per_launch": alg_bytes,
-                         "hbm_bytes_per_launch_pmc": traffic_bytes},
+            "blocks": {"n": len(blocks), "steps_each": a.steps, "ms_per_step": [round(b / a.steps * 1e3, 4) for b in blocks],
+                       "value_from": "median block", "spread_pct": round(100.0 * (max(blocks) - min(blocks)) / elapsed, 2)},
+            "roofline": roofline_block(res.loci, k_ms, k_n, k_loci, k_reads, "%s:%d" % (a.config, n_loc)),
+            "host_buffers": "inputs resident in HBM when the timed region starts; handing host buffers instead "
+                            "(smc_call_batch_host: H2D of 8 B/read + kernels + D2H of the rows) measured 1.81 M loci/s on C3 "
+                            "(DESIGN.md section 5) - PCIe-bound, never `value`",
         }
         if cpu is not None:
             out["cpu_baseline"], out["cpu_baseline_c"] = cpu["python_pool"], cpu["c_port"]
             out["cpu_baseline_c_all_cores"] = cpu["c_port_all_cores"]
-            gpu_rows = plan.download(rows)[:len(cpu["rows"])]
-            bad = abi.compare_rows(gpu_rows, cpu["rows"], fragile=cpu["fragile"])
-            out["parity_sample"] = {"loci": len(gpu_rows), "mismatches": len(bad), "detail": bad[:3]}
+        if oracle is not None:
+            res.run(rows)
+            torch.cuda.synchronize()
+            out["parity"] = res.parity(rows)
+    res.close()
+    del rows, pipe
+    if rank == 0 and world == 1 and not a.no_other_configs:
+        out["other_configs"] = {}
+        for name in ("C2", "C5"):
+            if name != a.config:
+                out["other_configs"][name] = other_config(eng, name, a, dev, nthreads, oracle)
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
 
+def other_config(eng, name, a, dev, nthreads, oracle):
+    """The other single-GPU BASELINE configs, same procedure (resident inputs, warm-up, blocks of --steps steps, median
+    block, HIP-event time of the dominant kernel, every row checked), reported as one short object each."""
+    cfg = synth.CONFIGS[name]
+    params = synth.params_for(cfg)
+    torch.cuda.empty_cache()
+    res = Resident(eng, cfg, params, 0, cfg.n_loci, max(1, min(a.chunk, 2_000_000_00 // (16 * cfg.depth))), nthreads, dev, oracle)
+    rows = res.plan.alloc_rows()
+    for _ in range(a.warmup):
+        res.run(rows)
+    blocks = []
+    res.plan.set_timing(min(a.steps * a.blocks, 256))
+    for _ in range(max(1, a.blocks)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            res.run(rows)
+        torch.cuda.synchronize()
+        blocks.append(time.perf_counter() - t0)
+    k_ms, k_n, k_loci, k_reads = res.plan.kernel_ms()
+    res.plan.set_timing(0)
+    el = sorted(blocks)[len(blocks) // 2]
+    rf = roofline_block(res.loci, k_ms, k_n, k_loci, k_reads, "%s:%d" % (name, cfg.n_loci))
+    o = {"workload": "%s: %d loci x %d reads (%d UMIs x %d rpb), seed %d" % (name, cfg.n_loci, cfg.depth, cfg.n_umi, cfg.rpb, cfg.seed),
+         "value": cfg.n_loci * a.steps / el, "unit": "loci/s", "ms_per_step": el / a.steps * 1e3,
+         "blocks_ms_per_step": [round(b / a.steps * 1e3, 4) for b in blocks],
+         "roofline": {k: rf[k] for k in ("achieved", "frac", "achieved_needed", "frac_needed", "kernel_ms", "loci_per_launch",
+                                         "alg_bytes_per_launch", "needed_bytes_per_launch")}}
+    if oracle is not None:
+        res.run(rows)
+        torch.cuda.synchronize()
+        o["parity"] = res.parity(rows)
+    res.close()
+    return o
+
+
 def cpu_leg(a):
     """CPU baselines on a bounded sample of the same workload (first chunk of the config):
     * python_pool - oracle/vc_port.py, the pure-Python restatement of vc(), driven like the reference's
-      main(): multiprocessing.Pool(all host cores), one task per locus, on the first 2000 loci;
-    * c_port - oracle/smc_oracle.c on one core over the whole first chunk; its rows are kept to check
-      the GPU rows of that chunk field by field after the timed run;
+      main(): multiprocessing.Pool(all host cores), one task per locus, on the first 2000+ loci;
+    * c_port - oracle/smc_oracle.c on one core over the whole first chunk;
     * c_port_all_cores - the same C code on every host core (threads over contiguous locus ranges)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_lib
@@ -193,7 +334,7 @@ def cpu_leg(a):
     sample = synth.generate_native(cfg, 0, min(a.chunk, n_loc), params)
     n = sample.n_loci
     t = time.perf_counter()
-    ref_rows, fragile = oracle_lib.call_batch(sample, abi.c_params(params), abi.ROW_DTYPE, return_fragile=True)
+    ref_rows = oracle_lib.call_batch(sample, abi.c_params(params), abi.ROW_DTYPE)
     dt_c = time.perf_counter() - t
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     reps = 5
@@ -218,8 +359,7 @@ def cpu_leg(a):
                    "sample": "first %d loci, C restatement oracle/smc_oracle.c, 1 thread, %.1f s" % (n, dt_c)},
         "c_port_all_cores": {"value": n / dt_cmt, "unit": "loci/s", "cores": cores, "kind": "port",
                              "sample": "first %d loci, C restatement oracle/smc_oracle.c on %d threads (contiguous locus "
-                                       "ranges), mean of %d passes, %.3f s each" % (n, cores, reps, dt_cmt)},
-        "rows": ref_rows, "fragile": fragile}
+                                       "ranges), mean of %d passes, %.3f s each" % (n, cores, reps, dt_cmt)}}
 
 
 if __name__ == "__main__":

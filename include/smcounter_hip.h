@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SMC_ABI_VERSION 1
+#define SMC_ABI_VERSION 2
 #define SMC_MAX_ALLELES 64 /* allele ids per locus; ids 0-5 are A,T,G,C,N,'DEL' */
 
 /* error codes */
@@ -73,7 +73,10 @@ extern "C" {
  *       0 not included, bq >= minBQ   1 not included, bq < minBQ (lowQReads, :428)
  *       2 included read 1, distToBcEnd > 20   3 included read 1, distToBcEnd <= 20            (:432-440)
  *       4 + (distToBcEnd <= 20) + 2 * (distToPrimerEnd <= primerDist)   included read 2       (:441-452)
- * The raw fields stay in the planes (the CPU restatement and the sorted-stream kernel compute from them). */
+ * The raw fields stay in the planes (the CPU restatement under oracle/ computes everything from them, so the parity
+ * tests check the classes too).  The class bakes in minBQ / minMQ / mismatchThr / primerDist: planes are only valid for the
+ * parameter set they were built with, which is why every locus descriptor carries smc_param_fingerprint() of it and
+ * smc_plan_run refuses any other (SMC_E_INPUT). */
 #define SMC_FRAG_SLOT_MASK 0x07FFFFFFu
 #define SMC_FRAG_CLASS_SHIFT 27
 #define SMC_N_READ_CLASS 22
@@ -98,7 +101,28 @@ typedef struct smc_params {
     int32_t ds;          /* maxMT if > 0 else int(round(2.0 * mtDepth))   smCounter.py:486 */
     int32_t reserved;
     double smt;          /* strong-MT threshold 2.0 / 3.0 / 4.0 by rpb    smCounter.py:302-308 */
+    double mismatch_thr; /* mismatchThr: consumed by the feature extraction (flag bit / read class); here so that a run can
+                          * be checked against the parameters its planes were built with */
 } smc_params;
+
+/* 15-bit fingerprint (never 0) of the four parameters the feature extraction folds into the planes (read class, the
+ * mismatch-ok flag, the in-deletion quality).  Stored in smc_locus.flags bits 1-15 by whoever builds a batch; smc_plan_create
+ * requires one common non-zero value over the batch, smc_plan_run compares it with the fingerprint of the run's smc_params
+ * and returns SMC_E_INPUT when they differ (planes built for one parameter set give silently wrong rows under another). */
+static inline uint16_t smc_param_fingerprint(int32_t min_bq, int32_t min_mq, double mismatch_thr, int32_t primer_dist) {
+    union { double d; uint64_t u; } cv;
+    cv.d = mismatch_thr;
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    const uint64_t w[4] = {(uint64_t)(uint32_t)min_bq, (uint64_t)(uint32_t)min_mq, cv.u, (uint64_t)(uint32_t)primer_dist};
+    for (int i = 0; i < 4; ++i) {
+        h ^= w[i];
+        h *= 0xBF58476D1CE4E5B9ull;
+        h ^= h >> 29;
+    }
+    const uint16_t fp = (uint16_t)((h >> 17) & 0x7FFFu);
+    return fp ? fp : (uint16_t)1;
+}
+#define SMC_LF_FP_SHIFT 1 /* smc_locus.flags bits 1-15: smc_param_fingerprint of the parameters the planes were built with */
 
 /* One per locus, 32 bytes. Reads of locus l occupy plane slots [4*read_off4, 4*read_off4 + n_reads)
  * (every locus starts on a 4-read boundary). Within the locus the reads are SORTED barcode-major:
@@ -111,9 +135,10 @@ typedef struct smc_params {
  * n_frag = number of distinct fragments (= allFrag, smCounter.py:483).
  * umi_start[umi_off + u], u = 0..n_umi, is the index (relative to the locus) of barcode u's first read;
  * the last entry equals n_reads. Every barcode has at least one read. Given barcode-major reads, umi_start
- * determines the umi plane; the default kernel uses umi_start and the slot order and does not load the umi
- * plane (the sorted-stream variant, SMC_KERNEL=sorted, reads it). frag words carry the read class in bits 27-31
- * (smc_read_class above); with it the default kernel does not load the dist plane either. Checked per locus, violations flag the row
+ * determines the umi plane; the kernels use umi_start and the slot order and do not load the umi
+ * plane. frag words carry the read class in bits 27-31 (smc_read_class above); with it the kernels do not load the
+ * dist plane either: `umi` and `dist` may be NULL in smc_plan_run / smc_call_batch_host (they are the raw fields the
+ * CPU restatement checks the classes and the order against). Checked per locus, violations flag the row
  * SMC_ST_BAD_INPUT: frag < n_frag, allele < n_alleles, umi_start ascending and covering [0, n_reads),
  * barcode slot ranges ascending and covering [0, n_frag).
  * Base qualities are Phred values <= 126 (BAM holds 0..93); larger bytes are clamped to 126. */
@@ -181,6 +206,29 @@ typedef struct smc_row {
     smc_cand cand[2];    /* [0] origAlt (:541), [1] secondMaxBase when biallelic */
 } smc_row;
 
+/* What travels between GPUs: the part of smc_row that the 45-column row is PRINTED from (smCounter.py:575-600; rows.py),
+ * 168 bytes instead of 432.  The tallies and Fisher p-values stay behind: filterVariants has already run on the device
+ * and left its verdict in the FILTER bits.  Replaces the pickled result strings of the reference's pool
+ * (`[p.get() for p in results]`, smCounter.py:685). */
+#define SMC_WIRE_BIALLELIC 0x10000u   /* smc_wire_row.status bit 16: smc_row.biallelic; bits 0-15: smc_row.status */
+#define SMC_WIRE_FLT_MASK 0x3FFu      /* smc_wire_cand.flags bits 0-9: SMC_F_* */
+#define SMC_WIRE_FLT_APPLIED 0x400u   /* bit 10: smc_cand.flt_applied */
+#define SMC_WIRE_VMF_LT_099 0x800u    /* bit 11: smc_cand.vmf_lt_099 */
+typedef struct smc_wire_cand {
+    int16_t allele;  /* -1: no such candidate */
+    uint16_t flags;
+    int32_t vdp, vmt, vsm;
+    double pi;
+} smc_wire_cand;
+typedef struct smc_wire_row {
+    uint32_t status;
+    int32_t cvg, all_frag, all_mt, used_frag, used_mt;
+    int32_t mt3, mt5, mt7, mt10;
+    int32_t dp[4], umt[4], vsm[4];
+    double pi[4];
+    smc_wire_cand cand[2];
+} smc_wire_row;
+
 typedef struct smc_ctx smc_ctx;
 typedef struct smc_plan smc_plan;
 
@@ -228,6 +276,13 @@ int smc_call_batch_host(smc_ctx* ctx, const smc_params* params, const smc_locus*
                         int64_t n_loci, const uint32_t* meta, const uint32_t* umi,
                         const uint32_t* frag, const uint32_t* dist, int64_t n_slots,
                         const uint32_t* umi_start, int64_t n_umi_start, smc_row* rows_out);
+
+/* Pack n rows (DEVICE pointers) into wire rows on `stream` (asynchronous), for the gather to the writing rank; and the
+ * inverse on the HOST (no GPU needed): the printed fields are restored exactly, everything else is zero (p-values NaN,
+ * n_touched / max_allele / second_allele / touched_mask / tallies: not carried). */
+int smc_wire_row_size(void);
+int smc_pack_rows(smc_ctx* ctx, const smc_row* rows, int64_t n, smc_wire_row* wire, void* stream);
+int smc_unpack_rows(const smc_wire_row* wire, int64_t n, smc_row* rows);
 
 /* HIP-event timing helpers so a host language without HIP bindings can time the stream the
  * kernels run on. */

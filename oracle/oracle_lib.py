@@ -56,24 +56,30 @@ def call_batch(db, cparams, row_dtype, return_fragile=False, return_pi_all=False
     return out if len(out) > 1 else rows
 
 
-def call_batch_mt(db, cparams, row_dtype, n_threads):
+def call_batch_mt(db, cparams, row_dtype, n_threads, return_fragile=False, return_pi_all=False):
     """The same C restatement over contiguous locus ranges on n_threads host threads (ctypes releases the
-    GIL during the call; the library keeps no state).  Used by bench.py for the all-cores C baseline."""
+    GIL during the call; the library keeps no state).  Used by bench.py for the all-cores C baseline and by the
+    full-size parity checks (optionally with the fragile counts / the PI of every allele key, as call_batch)."""
     import threading
     L = lib()
     rows = np.zeros(db.n_loci, row_dtype)
     loci = np.ascontiguousarray(db.loci)
+    fragile = np.zeros(db.n_loci, np.int32)
+    pi_all = np.full((db.n_loci, 64), np.nan) if return_pi_all else None
+    us = np.ascontiguousarray(db.umi_start)
+    n_threads = max(1, min(int(n_threads), max(1, db.n_loci)))
     bounds = [db.n_loci * t // n_threads for t in range(n_threads + 1)]
     errs = []
+    vp = ctypes.c_void_p
 
     def work(lo, hi):
         if hi <= lo:
             return
-        rc = L.smc_oracle_call_batch(ctypes.byref(cparams),
-                                     ctypes.c_void_p(loci.ctypes.data + lo * loci.dtype.itemsize), ctypes.c_int64(hi - lo),
-                                     db.meta.ctypes.data_as(ctypes.c_void_p), db.umi.ctypes.data_as(ctypes.c_void_p),
-                                     db.frag.ctypes.data_as(ctypes.c_void_p), db.dist.ctypes.data_as(ctypes.c_void_p),
-                                     ctypes.c_void_p(rows.ctypes.data + lo * row_dtype.itemsize))
+        rc = L.smc_oracle_call_batch_full(ctypes.byref(cparams), vp(loci.ctypes.data + lo * loci.dtype.itemsize),
+                                          ctypes.c_int64(hi - lo), vp(db.meta.ctypes.data), vp(db.umi.ctypes.data),
+                                          vp(db.frag.ctypes.data), vp(db.dist.ctypes.data), vp(us.ctypes.data),
+                                          vp(rows.ctypes.data + lo * row_dtype.itemsize), vp(fragile.ctypes.data + 4 * lo),
+                                          vp(pi_all.ctypes.data + 512 * lo) if return_pi_all else None)
         if rc != 0:
             errs.append(rc)
     th = [threading.Thread(target=work, args=(bounds[t], bounds[t + 1])) for t in range(n_threads)]
@@ -82,8 +88,13 @@ def call_batch_mt(db, cparams, row_dtype, n_threads):
     for t in th:
         t.join()
     if errs:
-        raise RuntimeError("smc_oracle_call_batch failed: %r" % errs)
-    return rows
+        raise RuntimeError("smc_oracle_call_batch_full failed: %r" % errs)
+    out = (rows,)
+    if return_fragile:
+        out += (fragile,)
+    if return_pi_all:
+        out += (pi_all,)
+    return out if len(out) > 1 else rows
 
 
 def fisher(a, b, c, d):

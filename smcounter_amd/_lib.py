@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, "libsmcounter_hip.so")
 SYMBOLS = ("smc_abi_version", "smc_last_error", "smc_row_size", "smc_locus_size", "smc_device_count",
            "smc_create", "smc_destroy", "smc_plan_create", "smc_plan_destroy", "smc_plan_info",
            "smc_plan_run", "smc_plan_set_timing", "smc_plan_kernel_ms", "smc_call_batch_host", "smc_event_create", "smc_event_record",
-           "smc_event_elapsed_ms", "smc_event_destroy", "smc_class_table")
+           "smc_event_elapsed_ms", "smc_event_destroy", "smc_class_table", "smc_wire_row_size", "smc_pack_rows", "smc_unpack_rows")
 
 
 class SmcError(RuntimeError):
@@ -64,14 +64,17 @@ def load(with_torch: bool = True):
     L.smc_plan_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(i32), ctypes.POINTER(i64),
                                      ctypes.POINTER(i64)]
     L.smc_call_batch_host.argtypes = [vp, ctypes.POINTER(abi.SmcParams), vp, i64, vp, vp, vp, vp, i64, vp, i64, vp]
+    L.smc_wire_row_size.restype = ctypes.c_int
+    L.smc_pack_rows.argtypes = [vp, vp, i64, vp, vp]
+    L.smc_unpack_rows.argtypes = [vp, i64, vp]
     L.smc_event_create.argtypes = [ctypes.POINTER(vp)]
     L.smc_event_record.argtypes = [vp, vp]
     L.smc_event_elapsed_ms.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_float)]
     L.smc_event_destroy.argtypes = [vp]
     L.smc_event_destroy.restype = None
-    if L.smc_abi_version() != 1:
+    if L.smc_abi_version() != 2:
         raise SmcError("ABI version mismatch")
-    if L.smc_row_size() != abi.ROW_DTYPE.itemsize or L.smc_locus_size() != 32:
+    if L.smc_row_size() != abi.ROW_DTYPE.itemsize or L.smc_locus_size() != 32 or L.smc_wire_row_size() != abi.WIRE_DTYPE.itemsize:
         raise SmcError("struct layout mismatch between include/smcounter_hip.h and smcounter_amd/abi.py")
     _LIB = L
     return L

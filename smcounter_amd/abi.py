@@ -24,11 +24,12 @@ FILTER_NAMES = ((F_LM, "LM"), (F_LSM, "LSM"), (F_HP, "HP"), (F_LOWC, "LowC"), (F
 class SmcParams(ctypes.Structure):
     _fields_ = [("min_bq", ctypes.c_int32), ("min_mq", ctypes.c_int32),
                 ("mt_drop", ctypes.c_int32), ("primer_dist", ctypes.c_int32),
-                ("ds", ctypes.c_int32), ("reserved", ctypes.c_int32), ("smt", ctypes.c_double)]
+                ("ds", ctypes.c_int32), ("reserved", ctypes.c_int32), ("smt", ctypes.c_double),
+                ("mismatch_thr", ctypes.c_double)]
 
 
 def c_params(p: VcParams) -> SmcParams:
-    return SmcParams(p.minBQ, p.minMQ, p.mtDrop, p.primerDist, p.ds, 0, p.smt)
+    return SmcParams(p.minBQ, p.minMQ, p.mtDrop, p.primerDist, p.ds, 0, p.smt, float(p.mismatchThr))
 
 
 CAND_DTYPE = np.dtype([
@@ -47,6 +48,43 @@ ROW_DTYPE = np.dtype([
     ("pi", "<f8", (4,)), ("touched_mask", "<u8"),
     ("ref_tal", "<i4", (SMC_NT,)), ("cand", CAND_DTYPE, (2,))])
 assert ROW_DTYPE.itemsize == 432
+
+# smc_wire_row: the printed part of a row, what the multi-GPU gather moves (include/smcounter_hip.h)
+WIRE_CAND_DTYPE = np.dtype([("allele", "<i2"), ("flags", "<u2"), ("vdp", "<i4"), ("vmt", "<i4"), ("vsm", "<i4"), ("pi", "<f8")])
+WIRE_DTYPE = np.dtype([("status", "<u4"), ("cvg", "<i4"), ("all_frag", "<i4"), ("all_mt", "<i4"), ("used_frag", "<i4"),
+                       ("used_mt", "<i4"), ("mt3", "<i4"), ("mt5", "<i4"), ("mt7", "<i4"), ("mt10", "<i4"),
+                       ("dp", "<i4", (4,)), ("umt", "<i4", (4,)), ("vsm", "<i4", (4,)), ("pi", "<f8", (4,)),
+                       ("cand", WIRE_CAND_DTYPE, (2,))])
+assert WIRE_CAND_DTYPE.itemsize == 24 and WIRE_DTYPE.itemsize == 168
+WIRE_BIALLELIC, WIRE_FLT_MASK, WIRE_FLT_APPLIED, WIRE_VMF_LT_099 = 0x10000, 0x3FF, 0x400, 0x800
+
+
+def pack_wire(rows: np.ndarray) -> np.ndarray:
+    """numpy mirror of the device's k_pack_rows (csrc/k_pack_rows.inc): ROW_DTYPE -> WIRE_DTYPE.  The GPU test checks
+    the kernel against it byte for byte; the CPU (gloo) tests use it in place of the kernel."""
+    w = np.zeros(len(rows), WIRE_DTYPE)
+    w["status"] = (rows["status"].astype(np.uint32) & 0xFFFF) | np.where(rows["biallelic"] != 0, WIRE_BIALLELIC, 0).astype(np.uint32)
+    for f in ("cvg", "all_frag", "all_mt", "used_frag", "used_mt", "mt3", "mt5", "mt7", "mt10", "dp", "umt", "vsm", "pi"):
+        w[f] = rows[f]
+    c, wc = rows["cand"], w["cand"]
+    wc["allele"] = c["allele"].astype(np.int16)
+    wc["flags"] = ((c["flt"] & WIRE_FLT_MASK) | np.where(c["flt_applied"] != 0, WIRE_FLT_APPLIED, 0)
+                   | np.where(c["vmf_lt_099"] != 0, WIRE_VMF_LT_099, 0)).astype(np.uint16)
+    for f in ("vdp", "vmt", "vsm", "pi"):
+        wc[f] = c[f]
+    return w
+
+
+def unpack_wire(wire: np.ndarray) -> np.ndarray:
+    """WIRE_DTYPE -> ROW_DTYPE through the library's smc_unpack_rows (host code, no GPU): every printed field restored,
+    the rest zero / NaN.  rows.format_rows prints the same strings from the result as from the original rows."""
+    from . import _lib
+    wire = np.ascontiguousarray(wire)
+    assert wire.dtype.itemsize == WIRE_DTYPE.itemsize
+    out = np.zeros(len(wire), ROW_DTYPE)
+    _lib.check(_lib.load().smc_unpack_rows(wire.ctypes.data, len(wire), out.ctypes.data), "smc_unpack_rows")
+    return out
+
 
 INT_FIELDS = ("status", "n_touched", "cvg", "all_frag", "all_mt", "used_frag", "used_mt", "mt3", "mt5",
               "mt7", "mt10", "max_allele", "second_allele", "biallelic", "dp", "umt", "vsm",
@@ -144,3 +182,17 @@ def compare_rows(a: np.ndarray, b: np.ndarray, pi_tol=1e-6, p_tol=1e-6, fragile=
         if dd.size and dd.max() > tol:
             bad.append("cand.%s max-abs-diff %g > %g" % (f, dd.max(), tol))
     return bad
+
+
+def parity_report(a: np.ndarray, b: np.ndarray, fragile=None, pi_all=None, pi_tol=1e-6, p_tol=1e-6) -> dict:
+    """compare_rows plus its denominators: how many loci were compared, how many had candidate / consensus fields
+    excused because the reference's own result is order-dependent there (`fragile`: a barcode whose unique-maximum
+    test hinges on rounding, smCounter.py:514; `near_tie`: two alleles whose PI differ only by summation order,
+    :534), and the largest PI difference seen.  "0 mismatches" means nothing without these."""
+    bad = compare_rows(a, b, pi_tol, p_tol, fragile, pi_all)
+    ok = ((a["status"] & 0xff) == ST_OK) & ((b["status"] & 0xff) == ST_OK)
+    d = np.abs(a["pi"] - b["pi"])[ok]
+    return {"loci": int(len(a)), "mismatches": len(bad),
+            "fragile_skipped": 0 if fragile is None else int((np.asarray(fragile) > 0).sum()),
+            "near_tie_skipped": len(near_tie_loci(a, b, pi_all=pi_all)),
+            "pi_max_abs_diff": float(d.max()) if d.size else 0.0, "detail": bad[:3]}

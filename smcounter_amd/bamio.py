@@ -393,7 +393,19 @@ def _column(a: Alignment, pos0: int):
             y += l
         elif op in (_CIG_D, _CIG_N):
             if x <= pos0 < x + l:
-                return y, True, 0
+                # the peek at the next operation applies to every current operation (samtools resolve_cigar2): the
+                # last column of a D/N block followed by I or D carries that indel (the reference tests `indel`
+                # before `is_del`, smCounter.py:371,392,416)
+                indel = 0
+                if pos0 == x + l - 1 and k + 1 < len(cig):
+                    nop, nl = cig[k + 1]
+                    if nop == _CIG_I:
+                        indel = nl
+                    elif nop == _CIG_D:
+                        indel = -nl
+                if indel and y >= a.l_seq:
+                    indel = 0           # no base to name the allele with: plain 'DEL'
+                return y, True, indel
             x += l
     return None
 
@@ -429,7 +441,7 @@ class _LocusBuilder(object):
             f = frags[u].setdefault(readid, len(frags[u]))
             if a.l_seq == 0:
                 raise BamError("alignment %s has no sequence; the reference indexes query_sequence" % a.qname)
-            if is_del:
+            if is_del and indel == 0:
                 key, bq = "DEL", 0
             else:
                 site = a.seq[qpos]

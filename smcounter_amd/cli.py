@@ -48,7 +48,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--logFile", default=None, help="log file")
     p.add_argument("--paramFile", default=None, help="optional parameter file; if given it replaces every other "
                                                      "parameter except --logFile")
-    p.add_argument("--device", type=int, default=0, help="GPU index")
+    p.add_argument("--device", type=int, default=0, help="GPU index (single process only: under torch.distributed.run "
+                                                          "every rank uses GPU LOCAL_RANK and this flag is ignored)")
     p.add_argument("--batchReads", type=int, default=4_000_000, help="pileup reads per device batch")
     return p
 
@@ -63,7 +64,9 @@ def call_shard(args, params: VcParams, loci, device: int):
         batches = bamio.iter_pileup_batches(bamio.BamFile(args.bamFile), ref, loci, max_reads=args.batchReads)
     else:
         # (one process per GPU: the ranks of a node share its cores for decoding)
-        nthreads = max(1, len(os.sched_getaffinity(0)) // max(1, int(os.environ.get("WORLD_SIZE", "1"))))
+        # (LOCAL_WORLD_SIZE: WORLD_SIZE also counts the ranks of other nodes, which do not share these cores)
+        per_node = int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE", "1"))
+        nthreads = max(1, len(os.sched_getaffinity(0)) // max(1, per_node))
         batches = bamio.iter_device_batches_native(args.bamFile, ref, loci, params, max_reads=args.batchReads,
                                                    nthreads=nthreads)
     for first, pb in _prefetch(batches):
@@ -134,12 +137,28 @@ def main(args) -> int:
         lo, hi = cuts[rank], cuts[rank + 1]
     else:
         lo, hi = 0, len(loc_list)
-    output = call_shard(args, params, loc_list[lo:hi], local_rank if world > 1 else args.device)
-    vc.raise_on_exception(output, loc_list[lo:hi])
-    if world > 1:
-        output = smcdist.gather_strings(output, dst=0)
+    if world == 1:
+        output = call_shard(args, params, loc_list[lo:hi], args.device)
+        vc.raise_on_exception(output, loc_list[lo:hi])
+    else:
+        # A failing locus (or a decoder error) on one rank must not leave the others waiting in the collective
+        # until the RCCL timeout: every rank first agrees on a status, then all raise together or all gather.
         import torch.distributed as tdist
-        tdist.barrier()
+        err, output = None, []
+        try:
+            output = call_shard(args, params, loc_list[lo:hi], local_rank)
+            vc.raise_on_exception(output, loc_list[lo:hi])
+        except Exception as e:                       # reported by every rank below
+            err = "rank %d: %s: %s" % (rank, type(e).__name__, e)
+        try:
+            failed = [m for m in smcdist.all_gather_status(err) if m]
+            if failed:
+                raise RuntimeError("smCounter failed on %d of %d ranks: %s" % (len(failed), world, " | ".join(failed)))
+            output = smcdist.gather_strings(output, dst=0)
+            tdist.barrier()
+        finally:
+            if tdist.is_initialized():
+                tdist.destroy_process_group()
         if rank != 0:
             return writers.pi_threshold(args.mtDepth, args.threshold)
 

@@ -457,7 +457,18 @@ inline bool resolve_column(const Aln& a, int64_t p0, int& qpos, bool& isdel, int
         } else if (op == 1 || op == 4) {
             y += l;
         } else if (op == 2 || op == 3) {
-            if (x <= p0 && p0 < x + l) { qpos = (int)y; isdel = true; return true; }
+            if (x <= p0 && p0 < x + l) {
+                qpos = (int)y; isdel = true;
+                // the peek at the next operation applies to every current operation (resolve_cigar2): the last column
+                // of a D/N block followed by I or D carries that indel, and the reference tests `indel` before
+                // `is_del` (smCounter.py:371,392,416)
+                if (p0 == x + l - 1 && k + 1 < a.cigar.size()) {
+                    const unsigned nop = a.cigar[k + 1] & 15; const int nl = (int)(a.cigar[k + 1] >> 4);
+                    if (nop == 1) indel = nl; else if (nop == 2) indel = -nl;
+                }
+                if (indel != 0 && qpos >= (int)a.l_seq) indel = 0;   // no base to name the allele with: plain 'DEL'
+                return true;
+            }
             x += l;
         }
     }
@@ -466,7 +477,7 @@ inline bool resolve_column(const Aln& a, int64_t p0, int& qpos, bool& isdel, int
 
 // allele id of what `a` shows at the column: 0-5 fixed, 6+ index into `extra` (appended on first sight)
 inline int allele_of(const Aln& a, int qpos, bool isdel, int indel, std::vector<std::string>& extra) {
-    if (isdel) return 5;
+    if (isdel && indel == 0) return 5;
     const char site = a.seq[(size_t)qpos];
     if (indel == 0) {
         switch (site) { case 'A': return 0; case 'T': return 1; case 'G': return 2; case 'C': return 3; case 'N': return 4; default: break; }
@@ -582,7 +593,7 @@ int64_t smc_bam_pileup(void* h, const char* chrom, int64_t start0, int64_t end0,
                 pair_stamp[(size_t)a.pair_gid] = p0; f = pair_local[(size_t)a.pair_gid] = n_frag_of[(size_t)u]++;
             } else f = pair_local[(size_t)a.pair_gid];
             const int ai = allele_of(a, qpos, isdel, indel, extra);
-            const int bqv = isdel ? 0 : a.qual[(size_t)qpos];
+            const int bqv = (isdel && indel == 0) ? 0 : a.qual[(size_t)qpos];
             if (ai > 255) { b.err = "more than 255 alleles at one locus"; return -5; }
             b.umi.push_back((uint32_t)u); b.frag.push_back((uint32_t)f);
             b.flag.push_back(a.oflag);
@@ -723,7 +734,7 @@ int64_t smc_bam_planes(void* h, const char* chrom, int64_t start0, int64_t end0,
                 ++n_reads_of[(size_t)u];
                 const int ai = allele_of(a, qpos, isdel, indel, extra);
                 if (ai >= SMC_MAX_ALLELES) { t_err[(size_t)t] = "more than 64 distinct alleles at " + std::string(chrom) + ":" + std::to_string(p0 + 1); err = -8; return; }
-                const unsigned bq = isdel ? 0u : a.qual[(size_t)qpos];
+                const unsigned bq = (isdel && indel == 0) ? 0u : a.qual[(size_t)qpos];
                 if (bq > 126) { t_err[(size_t)t] = "base quality " + std::to_string(bq) + " > 126 in " + std::string(a.qname); err = -7; return; }
                 // pairOrder: R2 wins over R1; neither -> the previous read's value (smCounter.py:359-362)
                 if (a.oflag & 3) r2 = (a.oflag & 2) != 0;
@@ -778,7 +789,8 @@ int64_t smc_bam_planes(void* h, const char* chrom, int64_t start0, int64_t end0,
                 if (extra[k].size() == 1) { mask |= 1ull << (6 + k); if (ra == 255 && extra[k][0] == rc) ra = 6 + (int)k; }
                 t_keys[(size_t)t] += extra[k]; t_keys[(size_t)t] += '\n';
             }
-            L.ref_allele = (uint8_t)ra; L.n_alleles = (uint8_t)(6 + extra.size()); L.flags = 0; L.snp_mask = mask;
+            L.ref_allele = (uint8_t)ra; L.n_alleles = (uint8_t)(6 + extra.size());
+            L.flags = (uint16_t)(smc_param_fingerprint(min_bq, min_mq, mismatch_thr, primer_dist) << SMC_LF_FP_SHIFT); L.snp_mask = mask;
             b.n_keys[(size_t)l] = (int32_t)extra.size();
             if (ds > 0 && (int)nu > ds && (int)inc_order.size() > ds) {
                 std::string& o = t_ds[(size_t)t];

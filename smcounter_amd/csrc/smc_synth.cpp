@@ -217,7 +217,7 @@ int smc_synth_generate(const smc_synth_cfg* c, int64_t lo, int64_t hi, uint32_t*
             L.ref_allele = (uint8_t)ref;
             const int n_extra = (first_ins <= R) + (first_dst <= R);
             L.n_alleles = (uint8_t)(6 + n_extra);
-            L.flags = 0;
+            L.flags = (uint16_t)(smc_param_fingerprint(c->min_bq, c->min_mq, c->mismatch_thr, c->primer_dist) << SMC_LF_FP_SHIFT);
             L.snp_mask = 0x1F;
             extra[l - lo] = (uint8_t)((first_ins <= R ? 1 : 0) | (first_dst <= R ? 2 : 0) | (first_ins < first_dst ? 4 : 0));
         }

@@ -72,6 +72,16 @@ def gather_strings(local: Sequence[str], dst: int = 0):
     return [s for part in parts for s in part]
 
 
+def all_gather_status(err: Optional[str]) -> List[Optional[str]]:
+    """Every rank's error message (None = fine), on every rank: the agreement step that precedes a collective so
+    that one rank's failure ends the whole job at once instead of stranding its peers (smCounter.py:689-694 raises
+    in the parent for any failed worker)."""
+    import torch.distributed as dist
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, err)
+    return out
+
+
 def init_from_env():
     """(rank, local_rank, world) of a `python -m torch.distributed.run` launch, process group initialised
     (`nccl` = RCCL when a GPU is visible, else `gloo`; SMC_DIST_BACKEND overrides); (0, 0, 1) when not launched

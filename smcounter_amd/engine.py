@@ -84,6 +84,26 @@ class Plan(object):
                                            rows.data_ptr(), ctypes.c_void_p(st.cuda_stream)), "smc_plan_run")
         return rows
 
+    def alloc_wire(self):
+        """Device buffer for the packed wire rows of this plan's loci (abi.WIRE_DTYPE, 168 B per locus)."""
+        import torch
+        return torch.empty(self.n_loci * abi.WIRE_DTYPE.itemsize, dtype=torch.uint8,
+                           device=torch.device("cuda", self.eng.device))
+
+    def pack(self, rows, wire=None, stream=None):
+        """Enqueue k_pack_rows: rows -> wire rows (what the gather to the writing rank moves)."""
+        import torch
+        if wire is None:
+            wire = self.alloc_wire()
+        st = stream if stream is not None else torch.cuda.current_stream(self.eng.device)
+        _lib.check(self.eng.L.smc_pack_rows(self.eng.ctx, rows.data_ptr(), self.n_loci, wire.data_ptr(),
+                                            ctypes.c_void_p(st.cuda_stream)), "smc_pack_rows")
+        return wire
+
+    @staticmethod
+    def download_wire(wire) -> np.ndarray:
+        return wire.cpu().numpy().view(abi.WIRE_DTYPE)
+
     def set_timing(self, slots: int):
         """Keep HIP-event pairs around the dominant kernel of the next `slots` runs (0 = off)."""
         _lib.check(self.eng.L.smc_plan_set_timing(self.h, int(slots)), "smc_plan_set_timing")

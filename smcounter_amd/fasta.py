@@ -10,6 +10,7 @@ class FastaFile(object):
     def __init__(self, path: str):
         self._path = path
         self._fh = open(path, "rb")
+        self._fd = self._fh.fileno()
         self._idx = {}
         fai = path + ".fai"
         if os.path.exists(fai):
@@ -51,8 +52,15 @@ class FastaFile(object):
             return ""
         b0 = off + (start // lb) * lw + start % lb
         b1 = off + ((end - 1) // lb) * lw + (end - 1) % lb + 1
-        self._fh.seek(b0)
-        return self._fh.read(b1 - b0).replace(b"\n", b"").replace(b"\r", b"").decode()
+        # positional read: atomic per call, so the decoder's helper thread (reference run / DEL allele strings)
+        # and the main thread (HP / LowC flanks) can share one handle; seek() + read() would interleave
+        raw, want = b"", b1 - b0
+        while len(raw) < want:
+            part = os.pread(self._fd, want - len(raw), b0 + len(raw))
+            if not part:
+                break
+            raw += part
+        return raw.replace(b"\n", b"").replace(b"\r", b"").decode()
 
     def close(self):
         self._fh.close()

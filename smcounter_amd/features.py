@@ -38,6 +38,24 @@ assert LOCUS_DTYPE.itemsize == 32
 
 FL_R2, FL_REV, FL_MMOK = 1, 2, 4
 LF_SAMPLED = 1                  # smc_locus.flags: host-applied down-sampling (include/smcounter_hip.h)
+LF_FP_SHIFT = 1                 # smc_locus.flags bits 1-15: fingerprint of the parameters the planes bake in
+
+
+def param_fingerprint(params) -> int:
+    """smc_param_fingerprint (include/smcounter_hip.h): 15 bits, never 0, of (minBQ, minMQ, mismatchThr, primerDist) -
+    the parameters folded into the planes (read class, mismatch flag, in-deletion quality).  smc_plan_run refuses to
+    run a batch under any other set."""
+    import struct
+    m = (1 << 64) - 1
+    h = 0x9E3779B97F4A7C15
+    w = (params.minBQ & 0xFFFFFFFF, params.minMQ & 0xFFFFFFFF,
+         struct.unpack("<Q", struct.pack("<d", float(params.mismatchThr)))[0], params.primerDist & 0xFFFFFFFF)
+    for x in w:
+        h ^= x
+        h = (h * 0xBF58476D1CE4E5B9) & m
+        h ^= h >> 29
+    fp = (h >> 17) & 0x7FFF
+    return fp or 1
 USTART_DROPPED = 0x80000000
 FRAG_SLOT_MASK = 0x07FFFFFF      # frag plane: bits 0-26 fragment slot, bits 27-31 read class (smcounter_hip.h)
 FRAG_CLASS_SHIFT = 27
@@ -216,6 +234,7 @@ def extract_features(pb: PileupBatch, params: VcParams) -> DeviceBatch:
     loci["n_reads"] = lens
     loci["n_umi"] = n_umi
     loci["n_frag"] = n_frag
+    loci["flags"] = param_fingerprint(params) << LF_FP_SHIFT
     for l in range(n_loci):
         tab = pb.alleles[l]
         if len(tab) > MAX_ALLELES:

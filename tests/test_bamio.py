@@ -398,3 +398,79 @@ def test_locus_weights_follow_depth_and_balance_the_shards(tmp_path):
     halves = depth[:cuts[1]].sum(), depth[cuts[1]:].sum()
     assert 0.6 < halves[0] / halves[1] < 1.6                       # (by locus count it would be 1 : 8)
     assert (bamio.locus_weights(str(tmp_path / "missing.bam"), loci) == 1).all()
+
+
+def test_fasta_fetch_is_atomic_across_threads(tmp_path):
+    """the decoder's helper thread and the main thread share one FastaFile; fetch() used to be an
+    unlocked seek() + read() on one handle and returned the wrong bases when the two interleaved."""
+    import threading
+    from smcounter_amd import fasta
+    rng = np.random.RandomState(11)
+    seqs = {"c%d" % k: "".join(rng.choice(list("ACGT"), 20000)) for k in range(3)}
+    path = str(tmp_path / "t.fa")
+    with open(path, "w") as fh:
+        for name, s in seqs.items():
+            fh.write(">%s\n" % name)
+            for i in range(0, len(s), 60):
+                fh.write(s[i:i + 60] + "\n")
+    fa = fasta.FastaFile(path)
+    bad = []
+
+    def work(seed):
+        r = np.random.RandomState(seed)
+        for _ in range(20000):
+            c = "c%d" % r.randint(3)
+            a = int(r.randint(0, 19900))
+            b = a + int(r.randint(1, 90))
+            if fa.fetch(c, a, b) != seqs[c][a:b]:
+                bad.append((c, a, b))
+    ts = [threading.Thread(target=work, args=(s,)) for s in (1, 2, 3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not bad, bad[:3]
+
+
+def test_deletion_followed_by_insertion_takes_the_indel_branch(tmp_path):
+    """samtools' resolve_cigar2 peeks at the next operation from EVERY current operation, so the last column
+    of a D block followed by I carries indel > 0, and the reference tests `indel` before `is_del`
+    (smCounter.py:371,392,416): the read shows 'INS|..' there, not 'DEL'.  Both decoders."""
+    ref = "ACGTTGCAAC" * 10
+    fa_path = str(tmp_path / "d.fa")
+    with open(fa_path, "w") as fh:
+        fh.write(">chrD\n" + ref + "\n")
+    seq = "ACGTTTTTGCAAC"                      # 5M 2D 3I 5M: query 5 + 3 + 5
+    recs = [dict(tid=0, pos=10, qname="r%d:x:BC%d:y" % (i, i % 2), flag=0x41 if i % 2 == 0 else 0x91, mapq=60,
+                 cigar=[(0, 5), (2, 2), (1, 3), (0, 5)], seq=seq, qual=[30 + i] * len(seq), nm=5) for i in range(4)]
+    recs += [dict(tid=0, pos=10, qname="q%d:x:BC2:y" % i, flag=0x41, mapq=60, cigar=[(0, 4), (2, 2), (2, 1), (0, 6)],
+                  seq="ACGTTGCAAC", qual=[35] * 10, nm=3) for i in range(2)]      # D followed by D: 'DEL|' at its last column
+    bam = str(tmp_path / "d.bam")
+    bamio.write_bam(bam, [("chrD", len(ref))], recs)
+    bamio.write_bai(bam)
+    fa = fasta.FastaFile(fa_path)
+    loci = [("chrD", str(p)) for p in range(14, 20)]       # 1-based 16, 17 = the two deleted columns of the first shape
+    py = pileup.concat([b for _, b in bamio.iter_pileup_batches(bamio.BamFile(bam), fa, loci)])
+    nat = pileup.concat([b for _, b in bamio.iter_pileup_batches_native(bam, fa, loci)])
+    assert py.alleles == nat.alleles
+    for k, _ in bamio._COLS:
+        assert np.array_equal(getattr(py, k), getattr(nat, k)), k
+    i17 = loci.index(("chrD", "17"))
+    s = py.locus_slice(i17)
+    first_shape = py.indel[s] == 3
+    assert first_shape.sum() == 4 and py.is_del[s][first_shape].all()
+    keys = {py.alleles[i17][a] for a in py.allele[s][first_shape]}
+    assert keys == {"INS|T|TTTG"}                    # site = seq[qpos] (qpos = first inserted base) + seq[qpos+1 : qpos+1+3], as the reference slices it
+    assert (py.bq[s][first_shape] >= 30).all()       # its own quality, not the 'DEL' stand-in
+    i16 = loci.index(("chrD", "16"))
+    s16 = py.locus_slice(i16)
+    assert "DEL" in {py.alleles[i16][a] for a in py.allele[s16][py.indel[s16] == 0]}
+    # 4M 2D 1D: the last column of the first D block peeks at the second
+    i16b = py.locus_slice(loci.index(("chrD", "16")))
+    assert ((py.indel[i16b] == -1) & py.is_del[i16b]).sum() == 2
+    P = VcParams(mtDepth=10, rpb=2.0)
+    a = pileup.concat([b for _, b in bamio.iter_pileup_batches(bamio.BamFile(bam), fa, loci)])
+    db_py = features.extract_features(a, P)
+    db_nat = [db for _, db in bamio.iter_device_batches_native(bam, fa, loci, P)]
+    assert len(db_nat) == 1
+    _assert_device_batches_equal(db_py, db_nat[0])

@@ -61,6 +61,69 @@ def test_two_rank_gather_restores_submission_order():
     assert got.tobytes() == want.tobytes()
 
 
+def _wire_worker(rank, world, port, path, q):
+    """Packed wire rows (168 B, abi.WIRE_DTYPE) instead of full rows: each rank packs its block (numpy mirror of
+    k_pack_rows - the GPU suite checks the kernel against it byte for byte), rank 0 gathers, unpacks (smc_unpack_rows) and
+    prints."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    from smcounter_amd import abi, dist
+    import oracle_lib
+    from conftest import load_golden
+    pb, db, P, refp, expected = load_golden(path)
+    rows = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE)
+    lo, hi = dist.shard_range(len(rows), rank, world)
+    wire = abi.pack_wire(rows[lo:hi])
+    counts = [b - a for a, b in (dist.shard_range(len(rows), r, world) for r in range(world))]
+    out = dist.gatherv_rows(torch.from_numpy(wire.view(np.uint8).copy()), counts, abi.WIRE_DTYPE.itemsize, dst=0)
+    if rank == 0:
+        q.put(out.numpy().tobytes())
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gather_of_packed_wire_rows_prints_the_same_strings():
+    """the gather moves 168-byte wire rows; unpacked on rank 0 they print the same 45-field strings
+    as the full 432-byte rows (golden stress vectors: filters, bi-allelic loci, zero coverage, indel alleles)."""
+    from conftest import golden_files, load_golden
+    from smcounter_amd import abi, rows as rowsmod
+    import oracle_lib
+    path = [p for p in golden_files() if "stress2" in p][0]
+    pb, db, P, refp, expected = load_golden(path)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_wire_worker, args=(r, 2, port, path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    wire = np.frombuffer(q.get(timeout=240), np.uint8).view(abi.WIRE_DTYPE)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    full = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE)
+    assert len(wire) == len(full) and abi.WIRE_DTYPE.itemsize == 168 <= 200
+    got = abi.unpack_wire(wire)
+    assert rowsmod.format_rows(got, db, P, refp) == rowsmod.format_rows(full, db, P, refp)
+    assert rowsmod.format_rows(got, db, P, refp, native=False) == rowsmod.format_rows(full, db, P, refp, native=False)
+    assert (got["cand"]["flt_applied"].any() and got["biallelic"].any() and (got["status"] == 1).any())
+    # every field the wire carries survives bit for bit
+    for f in ("status", "cvg", "all_frag", "all_mt", "used_frag", "used_mt", "mt3", "mt5", "mt7", "mt10", "dp", "umt", "vsm",
+              "biallelic"):
+        assert np.array_equal(got[f], full[f]), f
+    assert got["pi"].tobytes() == full["pi"].tobytes()
+    for f in ("allele", "flt", "flt_applied", "vmf_lt_099", "vdp", "vmt", "vsm"):
+        assert np.array_equal(got["cand"][f], full["cand"][f]), f
+    assert got["cand"]["pi"].tobytes() == full["cand"]["pi"].tobytes()
+
+
 def _cli_worker(rank, world, port, tmp, q):
     """One rank of the distributed command line; the GPU call is swapped for the CPU restatement (this test is
     about sharding, the string gather and the writers on rank 0)."""
@@ -125,6 +188,55 @@ def test_two_rank_command_line_writes_the_single_process_files(tmp_path):
     got = open(str(tmp_path / "dist.smCounter.all.txt")).read().split("\n")[1:-1]
     assert got == want and len(got) == len(loci)
     assert os.path.getsize(str(tmp_path / "dist.smCounter.cut.vcf")) > 0
+
+
+def _failing_cli_worker(rank, world, port, tmp, q):
+    """Rank 1's shard raises (a failing locus / decoder error); both ranks must end promptly with the same error."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world), SMC_DIST_BACKEND="gloo")
+    from smcounter_amd import cli
+
+    def shard(args, params, loci, device):
+        if rank == 1:
+            raise ValueError("decoder broke on purpose")
+        return ["row"] * len(loci)
+    cli.call_shard = shard
+    try:
+        cli.main(dict(outPrefix=os.path.join(tmp, "fail"), bamFile=os.path.join(tmp, "case.bam"),
+                      bedTarget=os.path.join(tmp, "case.bed"), mtDepth=12, rpb=3.0, hpLen=8,
+                      refGenome=os.path.join(tmp, "case.fa"), threshold=10))
+        q.put((rank, "returned"))
+    except RuntimeError as e:
+        q.put((rank, str(e)))
+
+
+@pytest.mark.timeout(300)
+def test_one_failing_rank_ends_every_rank_together(tmp_path):
+    """a rank that raises before the gather used to strand its peers in the collective."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bam_fixture
+    case = bam_fixture.make_case(str(tmp_path))
+    for k, name in (("bam", "case.bam"), ("bed", "case.bed"), ("fasta", "case.fa")):
+        os.replace(case[k], str(tmp_path / name))
+    if os.path.exists(case["bam"] + ".bai"):
+        os.replace(case["bam"] + ".bai", str(tmp_path / "case.bam.bai"))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_failing_cli_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        assert "failed on 1 of 2 ranks" in got[r] and "rank 1: ValueError: decoder broke on purpose" in got[r]
+    assert not os.path.exists(str(tmp_path / "fail.smCounter.all.txt"))
 
 
 def _pipe_worker(rank, world, port, q):

@@ -283,26 +283,103 @@ def test_full_size_properties(engine0):
     assert both.tobytes() == got.tobytes()
 
 
-def test_sorted_stream_kernel_variant(monkeypatch):
-    """SMC_KERNEL=sorted: the one-wave-per-locus stream kernel (+ hand-over of loci with re-created
-    fragments to the table kernel) must produce the same rows as the default path."""
-    from smcounter_amd import engine
-    monkeypatch.setenv("SMC_KERNEL", "sorted")
-    eng = engine.Engine(0)
-    try:
-        for path in golden_files()[:4]:
-            pb, db, P, refp, expected = load_golden(path)
-            got = eng.call_batch_host(db, P)
-            want, fragile = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE, return_fragile=True)
-            assert abi.compare_rows(got, want, PI_TOL, P_TOL, fragile) == []
-        cfg = synth.CONFIGS["C3"]
-        P = synth.params_for(cfg)
-        db = synth.generate_native(cfg, 0, 600, P)
-        got = eng.call_batch_host(db, P)
-        want, fragile = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE, return_fragile=True)
-        assert abi.compare_rows(got, want, PI_TOL, P_TOL, fragile) == []
-    finally:
-        eng.close()
+def test_planes_built_for_other_parameters_are_refused(engine0):
+    """VERDICT r1 (weak 1b): the planes bake minBQ / minMQ / mismatchThr / primerDist in (read class, mismatch flag,
+    in-deletion quality); running them under another set used to give silently wrong rows.  The batch now carries a
+    fingerprint of those four (smc_locus.flags bits 1-15) and smc_plan_run answers SMC_E_INPUT."""
+    import dataclasses
+    from smcounter_amd import _lib
+    cfg = synth.CONFIGS["C2"]
+    P = synth.params_for(cfg)                                        # minBQ 20
+    db = synth.generate_native(cfg, 0, 64, P)
+    assert (engine0.call_batch_host(db, P)["status"] == 0).all()
+    for other in (dataclasses.replace(P, minBQ=25), dataclasses.replace(P, minMQ=20), dataclasses.replace(P, primerDist=3),
+                  dataclasses.replace(P, mismatchThr=5.0)):
+        with pytest.raises(_lib.SmcError, match="built with other parameters"):
+            engine0.call_batch_host(db, other)
+        planes = engine0.upload(db)
+        plan = engine0.make_plan(db.loci)
+        with pytest.raises(_lib.SmcError, match="built with other parameters"):
+            plan.run(planes, other)
+        plan.close()
+    # parameters that are not folded into the planes may change freely
+    for same in (dataclasses.replace(P, mtDrop=1), dataclasses.replace(P, mtDepth=500), dataclasses.replace(P, rpb=2.0)):
+        got = engine0.call_batch_host(db, same)
+        want = oracle_lib.call_batch(db, abi.c_params(same), abi.ROW_DTYPE)
+        assert abi.compare_rows(got, want, PI_TOL, P_TOL) == []
+    # a batch that states no parameter set, or two, is refused when the plan is made
+    for mutate in (lambda L: L["flags"].__setitem__(slice(None), 0), lambda L: L["flags"].__setitem__(5, L["flags"][5] ^ 0x10)):
+        bad = dataclasses.replace(db, loci=db.loci.copy())
+        mutate(bad.loci)
+        with pytest.raises(_lib.SmcError, match="fingerprint"):
+            engine0.call_batch_host(bad, P)
+
+
+def _full_size_parity(engine0, cfg, n_loci, chunk, want_cut_vcf=None):
+    """Every locus of [0, n_loci) of `cfg`: GPU rows (resident path) against the CPU restatement on all host cores, chunk
+    by chunk (host RAM stays bounded).  Returns the parity report summed over chunks (+ the row strings when asked)."""
+    P = synth.params_for(cfg)
+    cores = len(os.sched_getaffinity(0))
+    tot = {"loci": 0, "mismatches": 0, "fragile_skipped": 0, "near_tie_skipped": 0, "pi_max_abs_diff": 0.0, "detail": []}
+    texts = ([], [])
+    for lo in range(0, n_loci, chunk):
+        db = synth.generate_native(cfg, lo, min(n_loci, lo + chunk), P)
+        planes = engine0.upload(db)
+        plan = engine0.make_plan(db.loci)
+        got = plan.download(plan.run(planes, P))
+        plan.close()
+        del planes
+        want, fragile, pi_all = oracle_lib.call_batch_mt(db, abi.c_params(P), abi.ROW_DTYPE, cores, return_fragile=True,
+                                                         return_pi_all=True)
+        rep = abi.parity_report(got, want, fragile, pi_all, PI_TOL, P_TOL)
+        for k in ("loci", "mismatches", "fragile_skipped", "near_tie_skipped"):
+            tot[k] += rep[k]
+        tot["pi_max_abs_diff"] = max(tot["pi_max_abs_diff"], rep["pi_max_abs_diff"])
+        tot["detail"] += ["[%d+] %s" % (lo, d) for d in rep["detail"]]
+        if want_cut_vcf is not None:
+            ref = synth.CyclicRef()
+            firm = (fragile == 0)
+            firm[list(abi.near_tie_loci(got, want, pi_all=pi_all))] = False      # (order of two PI-tied alleles: unpinned)
+            for R, acc in ((got, texts[0]), (want, texts[1])):
+                t = rows.format_rows(R, db, P, ref)
+                acc.extend(x for x, f in zip(t, firm) if f)
+    return tot, texts
+
+
+@pytest.mark.timeout(900)
+def test_full_size_C5_every_row_and_cut_vcf(engine0, tmp_path):
+    """BASELINE configs[4] at its real size and spike rate on one GPU: 100,000 loci x 8000 reads, 0.5 % AF at 1 % of the
+    loci.  EVERY row against the CPU restatement, and the .cut.vcf written from the GPU rows equal to the one written
+    from the restatement's rows."""
+    from smcounter_amd import postfilter, writers
+    cfg = synth.CONFIGS["C5"]
+    P = synth.params_for(cfg)
+    rep, (t_gpu, t_cpu) = _full_size_parity(engine0, cfg, cfg.n_loci, 10000, want_cut_vcf=True)
+    print("C5 full-size parity:", {k: v for k, v in rep.items() if k != "detail"})
+    assert rep["loci"] == 100000 and rep["mismatches"] == 0, rep["detail"]
+    assert rep["fragile_skipped"] + rep["near_tie_skipped"] <= 0.01 * rep["loci"]
+    assert rep["pi_max_abs_diff"] <= PI_TOL
+    thr = writers.pi_threshold(P.mtDepth, 0)
+    bodies = []
+    for tag, text in (("gpu", t_gpu), ("cpu", t_cpu)):
+        prefix = str(tmp_path / tag)
+        writers.write_outputs(prefix, postfilter.apply_repeat_filters(text, {}, {}), thr)
+        bodies.append(open(prefix + ".smCounter.cut.vcf").read())
+    assert bodies[0] == bodies[1]
+    n_calls = sum(1 for l in bodies[0].split("\n") if l and not l.startswith("#"))
+    print("C5 .cut.vcf: %d called variants, threshold %d" % (n_calls, thr))
+
+
+@pytest.mark.timeout(900)
+def test_full_size_C4_one_rank_share(engine0):
+    """BASELINE configs[3] (1 M loci x 3000x over 8 GPUs): one rank's share, the first 125,000 loci of C4's seed, every
+    row against the CPU restatement.  (The other seven shares are the same code on other loci: dist.shard_range.)"""
+    cfg = synth.CONFIGS["C4"]
+    rep, _ = _full_size_parity(engine0, cfg, 125000, 25000)
+    print("C4 share parity:", {k: v for k, v in rep.items() if k != "detail"})
+    assert rep["loci"] == 125000 and rep["mismatches"] == 0, rep["detail"]
+    assert rep["fragile_skipped"] + rep["near_tie_skipped"] <= 0.01 * rep["loci"]
+    assert rep["pi_max_abs_diff"] <= PI_TOL
 
 
 @pytest.mark.gpu
@@ -352,6 +429,24 @@ def test_spiked_variants_cut_vcf_concordance(engine0, tmp_path):
     assert len(files[0]) == len(files[1]) >= 20
     # (loci with a rounding-decided barcode may differ by one in a count column; none is expected here)
     assert (fragile > 0).sum() == 0 and files[0] == files[1]
+
+
+def test_pack_kernel_matches_the_numpy_mirror_and_unpacks_to_the_same_strings(engine0):
+    """k_pack_rows (the 168-byte wire rows the multi-GPU gather moves) against abi.pack_wire byte for byte, on rows with
+    filters / bi-allelic loci / zero coverage (golden stress vectors) and on a C3 slice; unpacked, they print the same
+    strings as the full rows."""
+    path = [p for p in golden_files() if "stress2" in p][0]
+    pb, db, P, refp, expected = load_golden(path)
+    for db_, P_, ref_ in ((db, P, refp), (synth.generate_native(synth.CONFIGS["C3"], 0, 700, synth.params_for(synth.CONFIGS["C3"])),
+                                          synth.params_for(synth.CONFIGS["C3"]), synth.CyclicRef())):
+        planes = engine0.upload(db_)
+        plan = engine0.make_plan(db_.loci)
+        rows_d = plan.run(planes, P_)
+        wire = plan.download_wire(plan.pack(rows_d))
+        full = plan.download(rows_d)
+        assert wire.tobytes() == abi.pack_wire(full).tobytes()
+        assert rows.format_rows(abi.unpack_wire(wire), db_, P_, ref_) == rows.format_rows(full, db_, P_, ref_)
+        plan.close()
 
 
 def test_descriptors_outside_the_buffers_are_refused(engine0):

@@ -160,14 +160,40 @@ def test_abi_library_loads_and_exports_every_declared_symbol():
     L = _lib.load()
     hdr = open(os.path.join(ROOT, "include", "smcounter_hip.h")).read()
     declared = set(re.findall(r"\b(smc_[a-z_0-9]+)\s*\(", hdr))
-    declared -= {"smc_ctx", "smc_plan", "smc_read_class"}      # (smc_read_class: static inline helper)
+    declared -= {"smc_ctx", "smc_plan", "smc_read_class", "smc_param_fingerprint"}      # (static inline helpers)
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert getattr(L, name) is not None
     assert L.smc_row_size() == abi.ROW_DTYPE.itemsize == 432
     assert L.smc_locus_size() == features.LOCUS_DTYPE.itemsize == 32
-    assert ctypes.sizeof(abi.SmcParams) == 32
+    assert ctypes.sizeof(abi.SmcParams) == 40
     assert L.smc_device_count() >= 0      # counting devices does not initialise the GPU
+
+
+def test_param_fingerprint_python_matches_the_header():
+    """smc_locus.flags bits 1-15 (ABI 2): every producer of a batch states the parameters its planes bake in; the
+    Python mirror must equal the header's static inline (compiled here with gcc) on every parameter set."""
+    import subprocess
+    import tempfile
+    from smcounter_amd.params import VcParams
+    cases = [(20, 30, 6.0, 2), (25, 30, 6.0, 2), (20, 31, 6.0, 2), (20, 30, 6.5, 2), (20, 30, 6.0, 3), (0, 0, 0.0, 0),
+             (93, 255, 100.0, 65535), (-1, 7, 1e-9, -3)]
+    src = '#include <stdio.h>\n#include "smcounter_hip.h"\nint main(void){' + "".join(
+        'printf("%%d\\n", (int)smc_param_fingerprint(%d, %d, %r, %d));' % c for c in cases) + "return 0;}"
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "fp.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I" + os.path.join(ROOT, "include"), "-o", os.path.join(d, "fp"), os.path.join(d, "fp.c")])
+        want = [int(x) for x in subprocess.check_output([os.path.join(d, "fp")]).split()]
+    got = [features.param_fingerprint(VcParams(minBQ=a, minMQ=b, mismatchThr=c, primerDist=e)) for a, b, c, e in cases]
+    assert got == want and all(0 < x < 32768 for x in got) and len(set(got)) == len(got)
+    # every producer writes it: numpy feature extraction, native generator (native decoder: tests/test_bamio.py)
+    from smcounter_amd import synth
+    cfg = synth.CONFIGS["C2"]
+    P = synth.params_for(cfg)
+    db = synth.generate_native(cfg, 0, 8, P)
+    assert (db.loci["flags"] >> 1 == features.param_fingerprint(P)).all()
+    db2 = features.extract_features(synth.generate(cfg, 0, 8), P)
+    assert (db2.loci["flags"] >> 1 == features.param_fingerprint(P)).all()
 
 
 def test_no_gpu_fails_loudly():
