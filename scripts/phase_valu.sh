@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 cd /tmp; export TMPDIR=/tmp
 F="-O3 --offload-arch=gfx950 -fPIC -shared -std=c++17 -ffp-contract=off -I$R/include"
 cp $R/smcounter_amd/libsmcounter_hip.so /tmp/lib_keep.so
-for ab in 1 2 3 5 4 0; do
+for ab in 1 2 3 4 0; do
   hipcc $F -DSMC_ABLATE=$ab -o $R/smcounter_amd/libsmcounter_hip.so $R/smcounter_amd/csrc/smcounter_hip.hip
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d $R/$out/a$ab -- python3 $R/scripts/quick_perf.py --cfg C3 --loci 40000 --iters 1 > /dev/null 2>&1
   python3 - $R/$out/a$ab $ab <<'PY'
@@ -15,7 +15,7 @@ d, ab = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(list)
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_call_loci" in r["Kernel_Name"]:
+        if "k_call_v2" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 print("ablate %s:" % ab, {k: round(sum(v) / len(v) / 40000) for k, v in sorted(acc.items())}, "per locus")
 PY

@@ -42,8 +42,7 @@
 
 // One translation unit; the parts:
 #include "device_common.inc"   // LDS header, DPP reductions, encodings, k_simple_table, finish_row (E stage)
-#include "k_call_loci.inc"     // kernel 1: scan + group + score + rank, one workgroup per locus
-#include "k_call_segments.inc" // kernel 1b: deep loci, one segment of whole barcodes at a time in a fixed LDS budget
+#include "k_call_v2.inc"       // kernel 1: scan + group + score + rank (whole loci; deep loci in parts and chunks)
 #include "k_filter_loci.inc"   // kernel 2: filterVariants / Fisher exact for the loci on the worklist
 #include "k_pack_rows.inc"     // kernel 3: rows -> 168-byte wire rows for the multi-GPU gather
 #include "host_abi.inc"        // the C ABI of include/smcounter_hip.h

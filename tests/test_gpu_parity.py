@@ -364,9 +364,10 @@ def test_full_size_C5_every_row_and_cut_vcf(engine0, tmp_path):
     for tag, text in (("gpu", t_gpu), ("cpu", t_cpu)):
         prefix = str(tmp_path / tag)
         writers.write_outputs(prefix, postfilter.apply_repeat_filters(text, {}, {}), thr)
-        bodies.append(open(prefix + ".smCounter.cut.vcf").read())
+        bodies.append([l for l in open(prefix + ".smCounter.cut.vcf") if not l.startswith("#")])   # (header lines name the prefix)
     assert bodies[0] == bodies[1]
-    n_calls = sum(1 for l in bodies[0].split("\n") if l and not l.startswith("#"))
+    n_calls = sum(1 for l in bodies[0] if l and not l.startswith("#"))
+    assert n_calls >= 5      # 1000 spiked loci, 0.5 % AF of 133 barcodes = 0.67 alt barcodes on average: few reach PI 16
     print("C5 .cut.vcf: %d called variants, threshold %d" % (n_calls, thr))
 
 
