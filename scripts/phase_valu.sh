@@ -4,7 +4,7 @@
 out=$1
 R=$GRAFT_REPO_ROOT
 cd /tmp; export TMPDIR=/tmp
-F="-O3 --offload-arch=gfx950 -fPIC -shared -std=c++17 -ffp-contract=off -I$R/include"
+F="-O3 --offload-arch=gfx950 -fPIC -shared -std=c++17 -ffp-contract=off -mllvm -disable-machine-licm -I$R/include"
 cp $R/smcounter_amd/libsmcounter_hip.so /tmp/lib_keep.so
 for ab in 1 2 3 4 0; do
   hipcc $F -DSMC_ABLATE=$ab -o $R/smcounter_amd/libsmcounter_hip.so $R/smcounter_amd/csrc/smcounter_hip.hip

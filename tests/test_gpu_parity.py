@@ -70,50 +70,70 @@ def test_stress_mix_of_sizes_and_bins(engine0):
     assert abi.compare_rows(got, want, PI_TOL, P_TOL, fragile) == []
 
 
-def test_huge_locus_uses_global_tables(engine0):
-    """Loci too large for LDS tables (> 160 KB): taken by k_call_segments, with the global-scratch bin behind it as the
-    hand-back (its slab shows in the plan's scratch size; test_segment_kernel_and_its_fallbacks runs that bin alone)."""
+def test_deep_locus_takes_the_parts_path(engine0):
+    """Loci beyond the whole-locus classes (> 24 k reads) are split into parts (shares of the barcodes, one workgroup each)
+    that add their headers into a global accumulator; the plan reports that scratch."""
     cfg = synth.SynthConfig("big", 2, 7000, 12, 99)
     P = synth.params_for(cfg)
     db = synth.generate_native(cfg, 0, 2, P)
-    assert 4 * int(db.loci["n_frag"][0]) > 160 * 1024
+    assert int(db.loci["n_reads"][0]) > 24576
     plan = engine0.make_plan(db.loci)
-    assert plan.info()[1] > 0                       # bytes of global scratch tables
+    assert plan.info()[1] > 0                       # bytes of accumulators + flag scratch
     got = engine0.call_batch_host(db, P)
     want, fragile = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE, return_fragile=True)
     assert abi.compare_rows(got, want, PI_TOL, P_TOL, fragile) == []
 
 
-def test_segment_kernel_and_its_fallbacks(monkeypatch):
-    """Loci beyond the LDS go through k_call_segments (whole barcodes, a fixed LDS budget per segment), and come back
-    to the global-table launch when it cannot take them.  (a) the same batch with and without the segment kernel
-    (SMC_NO_SEGMENTS is read when the plan is made): identical rows, equal to the CPU restatement; (b) one barcode
-    larger than a segment; (c) more barcodes than the cap without the host's sampling marks (the whole-locus stand-in);
-    (d) a contract violation inside a later segment; (e) host sampling marks across segments."""
+def test_parts_and_chunks_give_identical_rows(monkeypatch):
+    """Deep loci: several workgroups per locus ("parts") x chunks of whole barcodes per part.  Everything
+    a chunk produces is additive in integers, so the rows must be BIT-IDENTICAL however the locus is cut: (a) default
+    geometry, one workgroup for the whole locus, many small parts with tiny chunks, and the whole-locus class (no parts at
+    all); (b) one barcode larger than a chunk (its flag bytes go to global scratch); (c) more barcodes than the cap
+    without the host's sampling marks (the stand-in needs the whole locus: one workgroup takes it, chunk after chunk);
+    (d) a contract violation inside a later part; (e) host sampling marks across parts."""
     import dataclasses
     from smcounter_amd import engine
     cfg = synth.SynthConfig("big", 3, 7000, 12, 99)
     P = synth.params_for(cfg)
     db = synth.generate_native(cfg, 0, 3, P)
-    assert 4 * int(db.loci["n_frag"][0]) > 160 * 1024
+    assert int(db.loci["n_reads"][0]) > 24576
     want, fragile = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE, return_fragile=True)
     eng = engine.Engine(0)
-    seg = eng.call_batch_host(db, P)
-    monkeypatch.setenv("SMC_NO_SEGMENTS", "1")
-    glob = eng.call_batch_host(db, P)
-    monkeypatch.delenv("SMC_NO_SEGMENTS")
-    assert abi.compare_rows(seg, want, PI_TOL, P_TOL, fragile) == []
-    assert seg.tobytes() == glob.tobytes()                       # order-independent sums: bit-identical rows
-    # (b) 5 barcodes x 12,400 reads: ~8,600 fragment slots each, more than a segment holds (8,192).  (Not deeper: from
-    # ~6,700 unpaired fragments in ONE barcode on, the likelihood products of calProb leave the double range and what
-    # is left depends on the multiplication order - sequential in the reference, a tree here; no real barcode is near.)
+    base = eng.call_batch_host(db, P)
+    assert abi.compare_rows(base, want, PI_TOL, P_TOL, fragile) == []
+    geometries = [dict(SMC_DEEP_PART_READS="100000000"),                                         # one part, chunks of 16 k reads
+                  dict(SMC_DEEP_PART_READS="3000", SMC_DEEP_FCAP="512", SMC_DEEP_UCAP="97"),    # 28 parts, small chunks
+                  dict(SMC_DEEP_PART_READS="100000000", SMC_DEEP_FCAP="40", SMC_DEEP_UCAP="5"), # one part, ~600 chunks
+                  dict(SMC_DEEP_FROM_READS="100")]                                              # everything deep, incl. tiny loci
+    for env in geometries:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got = eng.call_batch_host(db, P)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert got.tobytes() == base.tobytes(), env
+    # the small shapes through the deep class as well (parts of a 300-read locus)
+    small = synth.generate_native(synth.CONFIGS["C2"], 0, 500, synth.params_for(synth.CONFIGS["C2"]))
+    Ps = synth.params_for(synth.CONFIGS["C2"])
+    ref_rows = eng.call_batch_host(small, Ps)
+    monkeypatch.setenv("SMC_DEEP_FROM_READS", "1"); monkeypatch.setenv("SMC_DEEP_PART_READS", "64"); monkeypatch.setenv("SMC_DEEP_FCAP", "16")
+    assert eng.call_batch_host(small, Ps).tobytes() == ref_rows.tobytes()
+    for k in ("SMC_DEEP_FROM_READS", "SMC_DEEP_PART_READS", "SMC_DEEP_FCAP"):
+        monkeypatch.delenv(k)
+    # (b) 5 barcodes x 12,400 reads each: one barcode is more than a 16 k-read chunk holds only with smaller chunks - force
+    # them: 8,600 fragments per barcode.  (Not deeper: from ~6,700 unpaired fragments in ONE barcode on, the likelihood
+    # products of calProb leave the double range and what is left depends on the multiplication order - sequential in the
+    # reference, a tree here; no real barcode is near.)
     cfg_b = synth.SynthConfig("giant2", 2, 5, 12400, 4322)
     Pb = synth.params_for(cfg_b)
     dbb = synth.generate_native(cfg_b, 0, 2, Pb)
-    assert 4 * int(dbb.loci["n_frag"][0]) > 160 * 1024 and int(dbb.loci["n_frag"][0]) // 5 > 8192 + 200
-    got = eng.call_batch_host(dbb, Pb)
     wb, fb = oracle_lib.call_batch(dbb, abi.c_params(Pb), abi.ROW_DTYPE, return_fragile=True)
+    got = eng.call_batch_host(dbb, Pb)
     assert abi.compare_rows(got, wb, PI_TOL, P_TOL, fb) == []
+    monkeypatch.setenv("SMC_DEEP_FCAP", "1024")               # 4 k reads per chunk < 12.4 k reads of one barcode
+    got2 = eng.call_batch_host(dbb, Pb)
+    monkeypatch.delenv("SMC_DEEP_FCAP")
+    assert got2.tobytes() == got.tobytes()
     # (c) ds = 2 * mtDepth below the barcode count, no marks
     Pc = dataclasses.replace(P, mtDepth=1000)
     got = eng.call_batch_host(db, Pc)
@@ -126,7 +146,7 @@ def test_segment_kernel_and_its_fallbacks(monkeypatch):
     bad.frag[o] = (bad.frag[o] & ~np.uint32(features.FRAG_SLOT_MASK)) | np.uint32(int(db.loci["n_frag"][1]) + 7)
     got = eng.call_batch_host(bad, P)
     assert got["status"][1] & abi.ST_BAD_INPUT
-    assert got[[0, 2]].tobytes() == seg[[0, 2]].tobytes()
+    assert got[[0, 2]].tobytes() == base[[0, 2]].tobytes()
     # (e) marks: drop every third barcode of locus 0 down to exactly ds
     Pe = dataclasses.replace(P, mtDepth=2500)                   # ds = 5000 < 7000
     us = db.umi_start.copy()
@@ -145,8 +165,8 @@ def test_segment_kernel_and_its_fallbacks(monkeypatch):
 
 
 def test_locus_above_2_to_18_reads(engine0):
-    """312,000 reads on one locus (the table kernel takes up to 2^24; pysam's max_depth in the reference is 10^6):
-    tables in the global scratch slab, rows equal to the CPU restatement."""
+    """312,000 reads on one locus (the kernel takes up to 2^24; pysam's max_depth in the reference is 10^6): 22 parts,
+    rows equal to the CPU restatement."""
     cfg = synth.SynthConfig("deep", 2, 5200, 60, 777)
     P = synth.params_for(cfg)
     db = synth.generate_native(cfg, 0, 2, P)
@@ -158,7 +178,7 @@ def test_locus_above_2_to_18_reads(engine0):
 
 
 def test_long_scan_and_giant_barcode(engine0):
-    """(a) a 128-thread locus scanned in more than 7 steps: the packed 5-bit tally accumulators are spilled on the
+    """(a) a locus scanned in more than 7 steps per wavefront: the packed 5-bit tally accumulators are widened on the
     way; (b) a barcode with more fragments than the per-count posterior table holds (>= 4096): scored by the general
     path although it shows one allele."""
     cfg = synth.SynthConfig("steps8", 40, 70, 60, 1234)
