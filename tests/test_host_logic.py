@@ -431,3 +431,73 @@ def test_compare_rows_recognises_ties_with_alleles_outside_the_row():
     assert abi.compare_rows(a, b, pi_all=pi_all) == []                      # tie within 1e-9: order not pinned
     pi_all[:, 7] = 4.7
     assert abi.compare_rows(a, b, pi_all=pi_all) != []                      # a real difference is still reported
+
+
+def _py2_pin_lib():
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    L = ctypes.CDLL(os.path.join(ROOT, "oracle", "libpy2_pin.so"))
+    L.py2pin_str_hash.restype = ctypes.c_int64
+    L.py2pin_str_hash.argtypes = [ctypes.c_char_p, ctypes.c_int64]
+    return L
+
+
+def test_py2_emulation_against_the_independent_c_restatement():
+    """smcounter_amd/py2compat.py (what the product AND the harnessed reference use for
+    `random.seed(pos); random.sample(bcDict.keys(), ds)`, smCounter.py:496-498) against oracle/py2_pin.c, a second
+    restatement of CPython 2.7's string hash, dict insertion / resize / key order, MT19937 seeding from a str and
+    random.sample, written separately from the published interpreter sources (its own MT19937 too - py2compat leans on this
+    interpreter's).  10^4 random barcode sets, sizes concentrated around the resize boundaries of the table (5 -> 6,
+    21 -> 22, 85 -> 86, 341 -> 342, 1365 -> 1366 keys) and both branches of sample() (pool swaps up to `setsize`,
+    index rejection above)."""
+    from smcounter_amd import py2compat as p
+    L = _py2_pin_lib()
+    rng = np.random.RandomState(20170410)
+
+    def c_strings(strs):
+        bs = [s.encode("latin-1") for s in strs]
+        arr = (ctypes.c_char_p * len(bs))(*bs)
+        lens = (ctypes.c_int64 * len(bs))(*[len(b) for b in bs])
+        return arr, lens
+
+    # string hash incl. the empty string and high bytes
+    for s in ["", "a", "ACGTACGTAC", "x" * 300, "\xff\xfe", "AAAAAAAAAAAA", "chr17:41243700"] + \
+             ["".join(rng.choice(list("ACGT"), int(rng.randint(1, 20)))) for _ in range(300)]:
+        b = s.encode("latin-1")
+        assert L.py2pin_str_hash(b, len(b)) == p.py2_str_hash(s), s
+    # the generator after seed(str): the stream itself
+    for s in ["41243700", "1", "", "999999999", "chrS:12"]:
+        out = (ctypes.c_double * 50)()
+        b = s.encode()
+        L.py2pin_random_after_seed(b, len(b), 50, out)
+        r = p.Py2Random(s)
+        assert list(out) == [r.random() for _ in range(50)], s
+    sizes = [1, 2, 4, 5, 6, 7, 20, 21, 22, 23, 84, 85, 86, 87, 340, 341, 342, 343, 1364, 1365, 1366, 1367]
+    n_sets = 0
+    branch = {"pool": 0, "reject": 0}
+    for it in range(10000):
+        n = int(rng.choice(sizes)) if it % 4 else int(rng.randint(1, 2500))
+        if n > 400 and it % 10:
+            n = int(rng.choice(sizes[:14]))                       # keep the bulk small: 10^4 sets in seconds
+        L_bc = int(rng.choice([8, 10, 12, 14]))
+        seen, names = set(), []
+        while len(names) < n:
+            s = "".join(rng.choice(list("ACGT"), L_bc))
+            if s not in seen:
+                seen.add(s)
+                names.append(s)
+        arr, lens = c_strings(names)
+        order = (ctypes.c_int32 * n)()
+        assert L.py2pin_dict_order(arr, lens, n, order) == 0
+        assert [names[i] for i in order] == p.py2_dict_order(names), (it, n)
+        if n >= 2:
+            ds = int(rng.randint(1, n))
+            pos = str(int(rng.randint(1, 250_000_000)))
+            out = (ctypes.c_int32 * ds)()
+            pb = pos.encode()
+            assert L.py2pin_downsample(pb, len(pb), arr, lens, n, ds, out) == 0
+            assert [names[i] for i in out] == p.py2_downsample_barcodes(pos, names, ds), (it, n, ds)
+            setsize = 21 + (4 ** np.ceil(np.log(ds * 3) / np.log(4)) if ds > 5 else 0)
+            branch["pool" if n <= setsize else "reject"] += 1
+        n_sets += 1
+    assert n_sets == 10000 and branch["pool"] > 1000 and branch["reject"] > 1000, branch
