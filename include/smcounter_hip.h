@@ -80,7 +80,12 @@ extern "C" {
 #define SMC_FRAG_SLOT_MASK 0x07FFFFFFu
 #define SMC_FRAG_CLASS_SHIFT 27
 #define SMC_N_READ_CLASS 22
-static inline uint32_t smc_read_class(int kind, int rev, int r2, int inc, int bq_ok, int le20, int prle) {
+#if defined(__HIPCC__)
+#define SMC_HOST_DEVICE __host__ __device__   /* (the device plane builder evaluates it too) */
+#else
+#define SMC_HOST_DEVICE
+#endif
+SMC_HOST_DEVICE static inline uint32_t smc_read_class(int kind, int rev, int r2, int inc, int bq_ok, int le20, int prle) {
     if (kind == 1) return (uint32_t)(0 + (inc ? 1 : 0));
     if (kind != 0) return (uint32_t)(2 + (rev ? 2 : 0) + (inc ? 1 : 0));
     uint32_t sub;
@@ -229,6 +234,26 @@ typedef struct smc_wire_row {
     smc_wire_cand cand[2];
 } smc_wire_row;
 
+/* ---- input of the device plane builder (smc_build_planes): a run's alignments as a structure of arrays, one entry per
+ * ALIGNMENT, produced by the decoder (libsmc_bam.so: smc_bam_alignments, smcounter_host.h) */
+#define SMC_DA_R1 1u
+#define SMC_DA_R2 2u
+#define SMC_DA_REV 4u
+#define SMC_DA_MMOK 16u /* mismatchPer100b <= mismatchThr (smCounter.py:352-356, third term of incCond :378) */
+typedef struct smc_dev_aln {
+    int32_t pos, end;          /* 0-based reference span [pos, end) */
+    uint32_t cig_off, seq_off; /* first CIGAR word / first base (and quality) in the pools */
+    uint16_t n_cig;
+    uint8_t oflag, mapq;
+    uint16_t left_sp, qalen;   /* leading soft clip, query_alignment_length (:336-349, :434-448) */
+    uint16_t l_seq, pad;
+    uint32_t bc_gid, pair_gid; /* run-wide ids of the barcode and of (barcode, read id), dense, in file order */
+} smc_dev_aln;
+typedef struct smc_dev_locus {
+    uint32_t w0, w1;           /* alignments [w0, w1) are the candidates that can cover the locus */
+    uint32_t slot_off, n;      /* first (4-aligned) read slot of the locus in the run's planes, pileup depth */
+} smc_dev_locus;
+
 typedef struct smc_ctx smc_ctx;
 typedef struct smc_plan smc_plan;
 
@@ -283,6 +308,29 @@ int smc_call_batch_host(smc_ctx* ctx, const smc_params* params, const smc_locus*
 int smc_wire_row_size(void);
 int smc_pack_rows(smc_ctx* ctx, const smc_row* rows, int64_t n, smc_wire_row* wire, void* stream);
 int smc_unpack_rows(const smc_wire_row* wire, int64_t n, smc_row* rows);
+
+/* Build the planes of a run ON THE DEVICE from its alignments (the device half of the feature extraction; the host half is
+ * smc_bam_alignments): per locus the covering alignments in file order, per read the CIGAR walk, allele, quality, flags,
+ * end distances and read class (smCounter.py:316-366, :371-452), barcode / fragment ids by first appearance (:462-471),
+ * the barcode-major order, umi_start and the descriptor - byte for byte what smc_bam_planes builds on the host.
+ * Everything in `in` and every output is a DEVICE pointer.  Outputs: the four planes (the run's slots start at
+ * slot_base), umi_start / u_gid / u_finc (sized slots + loci of the batch; locus l of the run uses
+ * [umi_base + slot_off(l) + l, ... + n_umi(l)]; u_gid / u_finc - run-wide barcode id and first INCLUDED pileup index per
+ * barcode - are filled only for loci with more barcodes than params->ds: what the host needs for the reference's
+ * down-sampling, :496-498), loci[n_loci] (read_off4 / umi_off already batch-relative), and for every allele beyond the six
+ * fixed ones five words in xlist (locus, allele id, alignment, query position, indel; smc_bam_allele_key turns them into the
+ * key text).  counters[0] = entries appended to xlist, counters[1] = status bits (0 = fine; see csrc/k_build_planes.inc:
+ * 1 depth mismatch / more than smc_build_max_depth() reads at a locus, 2 extras overflow, 4 base quality > 126, 8 more
+ * than 64 alleles) - the caller falls back to smc_bam_planes for the run when it is not 0.  Asynchronous on `stream`. */
+typedef struct smc_build_in {
+    const smc_dev_aln* aln; const uint32_t* cig; const uint8_t* seq; const uint8_t* qual;
+    const smc_dev_locus* loc; const uint8_t* refseq;
+    int32_t start0, n_loci, n_bc, n_pair;
+} smc_build_in;
+int smc_build_max_depth(void);
+int smc_build_planes(smc_ctx* ctx, const smc_params* params, const smc_build_in* in, uint32_t slot_base, uint32_t umi_base,
+                     uint32_t* meta, uint32_t* umi, uint32_t* frag, uint32_t* dist, uint32_t* umi_start, uint32_t* u_gid,
+                     uint32_t* u_finc, smc_locus* loci, uint32_t* xlist, uint32_t xcap, uint32_t* counters, void* stream);
 
 /* HIP-event timing helpers so a host language without HIP bindings can time the stream the
  * kernels run on. */

@@ -55,6 +55,18 @@ int64_t smc_bam_planes(void* h, const char* chrom, int64_t start0, int64_t end0,
 void smc_bam_planes_copy(void* h, uint32_t* umi_start, int32_t* n_keys, char* keys);
 const char* smc_bam_ds_info(void* h);
 
+/* ---- device plane builder, host half (the device half is smc_build_planes in smcounter_hip.h): the run's alignments as a
+ * structure of arrays - decode only, one entry per alignment; the per-pileup-read work of smCounter.py:316-366, :371-452
+ * and :462-471 happens on the GPU.  Replaces, for this path, what the reference takes from pysam's AlignedSegment
+ * objects. */
+/* (smc_dev_aln / smc_dev_locus: smcounter_hip.h - the HIP library reads them) */
+typedef void (*smc_aln_alloc)(void* ctx, int64_t n_aln, int64_t n_cig, int64_t n_seq, int64_t n_loci, void** out);
+int64_t smc_bam_alignments(void* h, const char* chrom, int64_t start0, int64_t end0, int64_t max_reads, double mismatch_thr,
+                           int nthreads, smc_aln_alloc alloc, void* alloc_ctx, int64_t* n_loci_done, int64_t* n_slots,
+                           int32_t* n_bc, int32_t* n_pair, int32_t* status);
+int smc_bam_allele_key(void* h, int64_t aln_index, int32_t qpos, int32_t indel, char* out, int cap);
+const char* smc_bam_barcode_name(void* h, int32_t gid);
+
 /* ---------------------------------------------------------------- libsmc_rowfmt.so */
 
 /* Upper bound of one printed line of smc_format_tails. */

@@ -13,7 +13,8 @@ LIB_PATH = os.path.join(HERE, "libsmcounter_hip.so")
 SYMBOLS = ("smc_abi_version", "smc_last_error", "smc_row_size", "smc_locus_size", "smc_device_count",
            "smc_create", "smc_destroy", "smc_plan_create", "smc_plan_destroy", "smc_plan_info",
            "smc_plan_run", "smc_plan_set_timing", "smc_plan_kernel_ms", "smc_call_batch_host", "smc_event_create", "smc_event_record",
-           "smc_event_elapsed_ms", "smc_event_destroy", "smc_class_table", "smc_wire_row_size", "smc_pack_rows", "smc_unpack_rows")
+           "smc_event_elapsed_ms", "smc_event_destroy", "smc_class_table", "smc_wire_row_size", "smc_pack_rows", "smc_unpack_rows",
+           "smc_build_planes", "smc_build_max_depth")
 
 
 class SmcError(RuntimeError):
@@ -67,6 +68,9 @@ def load(with_torch: bool = True):
     L.smc_wire_row_size.restype = ctypes.c_int
     L.smc_pack_rows.argtypes = [vp, vp, i64, vp, vp]
     L.smc_unpack_rows.argtypes = [vp, i64, vp]
+    L.smc_build_max_depth.restype = ctypes.c_int
+    L.smc_build_planes.argtypes = [vp, ctypes.POINTER(abi.SmcParams), ctypes.POINTER(abi.SmcBuildIn), ctypes.c_uint32,
+                                   ctypes.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_uint32, vp, vp]
     L.smc_event_create.argtypes = [ctypes.POINTER(vp)]
     L.smc_event_record.argtypes = [vp, vp]
     L.smc_event_elapsed_ms.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_float)]

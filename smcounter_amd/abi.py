@@ -28,6 +28,20 @@ class SmcParams(ctypes.Structure):
                 ("mismatch_thr", ctypes.c_double)]
 
 
+class SmcBuildIn(ctypes.Structure):
+    """smc_build_in (include/smcounter_hip.h): device pointers to a run's alignment arrays."""
+    _fields_ = [("aln", ctypes.c_void_p), ("cig", ctypes.c_void_p), ("seq", ctypes.c_void_p), ("qual", ctypes.c_void_p),
+                ("loc", ctypes.c_void_p), ("refseq", ctypes.c_void_p), ("start0", ctypes.c_int32), ("n_loci", ctypes.c_int32),
+                ("n_bc", ctypes.c_int32), ("n_pair", ctypes.c_int32)]
+
+
+DEV_ALN_DTYPE = np.dtype([("pos", "<i4"), ("end", "<i4"), ("cig_off", "<u4"), ("seq_off", "<u4"), ("n_cig", "<u2"),
+                          ("oflag", "u1"), ("mapq", "u1"), ("left_sp", "<u2"), ("qalen", "<u2"), ("l_seq", "<u2"),
+                          ("pad", "<u2"), ("bc_gid", "<u4"), ("pair_gid", "<u4")])
+DEV_LOCUS_DTYPE = np.dtype([("w0", "<u4"), ("w1", "<u4"), ("slot_off", "<u4"), ("n", "<u4")])
+assert DEV_ALN_DTYPE.itemsize == 36 and DEV_LOCUS_DTYPE.itemsize == 16
+
+
 def c_params(p: VcParams) -> SmcParams:
     return SmcParams(p.minBQ, p.minMQ, p.mtDrop, p.primerDist, p.ds, 0, p.smt, float(p.mismatchThr))
 

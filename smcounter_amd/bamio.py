@@ -531,6 +531,8 @@ _NATIVE = None
 import ctypes as _C
 # allocation callback of smc_bam_planes: (ctx, n_slots, n_loci, void* out[5])
 _PLANES_ALLOC = _C.CFUNCTYPE(None, _C.c_void_p, _C.c_int64, _C.c_int64, _C.POINTER(_C.c_void_p))
+# allocation callback of smc_bam_alignments: (ctx, n_aln, n_cig, n_seq, n_loci, void* out[5])
+_ALN_ALLOC = _C.CFUNCTYPE(None, _C.c_void_p, _C.c_int64, _C.c_int64, _C.c_int64, _C.c_int64, _C.POINTER(_C.c_void_p))
 
 
 def _native_lib():
@@ -555,6 +557,13 @@ def _native_lib():
         lib.smc_bam_ds_info.restype = C.c_char_p
         lib.smc_bam_planes.restype = C.c_int64
         lib.smc_bam_planes_copy.argtypes = [C.c_void_p] * 4
+        lib.smc_bam_alignments.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_int,
+                                           _ALN_ALLOC, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                           C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        lib.smc_bam_alignments.restype = C.c_int64
+        lib.smc_bam_allele_key.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_char_p, C.c_int]
+        lib.smc_bam_barcode_name.argtypes = [C.c_void_p, C.c_int32]
+        lib.smc_bam_barcode_name.restype = C.c_char_p
         _NATIVE = lib
     return _NATIVE
 
@@ -619,6 +628,44 @@ class NativeBam(object):
                     tables[l].append(key)
                 k += int(n_keys[l])
         return tables
+
+    def alignments_run(self, chrom: str, lo: int, hi: int, max_reads: int, params, nthreads: int):
+        """Host half of the device plane builder (smc_bam_alignments): the run's alignments as a structure of arrays -
+        dict(aln, cig, seq, qual, loc, nl, n_slots, n_bc, n_pair, status, reads).  The handle keeps the run's records:
+        `allele_key` / `barcode_name` refer to them until the next call."""
+        import ctypes as C
+        from .abi import DEV_ALN_DTYPE, DEV_LOCUS_DTYPE
+        got = {}
+
+        def alloc(ctx, n_aln, n_cig, n_seq, n_loci, out):
+            got["aln"] = np.empty(n_aln, DEV_ALN_DTYPE)
+            got["cig"] = np.empty(max(1, n_cig), np.uint32)
+            got["seq"] = np.empty(max(1, n_seq), np.uint8)
+            got["qual"] = np.empty(max(1, n_seq), np.uint8)
+            got["loc"] = np.empty(n_loci, DEV_LOCUS_DTYPE)
+            for k, name in enumerate(("aln", "cig", "seq", "qual", "loc")):
+                out[k] = got[name].ctypes.data
+        cb = _ALN_ALLOC(alloc)
+        done, n_slots = C.c_int64(0), C.c_int64(0)
+        n_bc, n_pair, status = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        n = self._lib.smc_bam_alignments(self._h, chrom.encode(), lo, hi, max_reads, float(params.mismatchThr), int(nthreads),
+                                         cb, None, C.byref(done), C.byref(n_slots), C.byref(n_bc), C.byref(n_pair),
+                                         C.byref(status))
+        if n < 0:
+            raise BamError(self._lib.smc_bam_error(self._h).decode())
+        got.update(nl=done.value, n_slots=n_slots.value, n_bc=n_bc.value, n_pair=n_pair.value, status=status.value, reads=n)
+        return got
+
+    def allele_key(self, ai: int, qpos: int, indel: int) -> str:
+        import ctypes as C
+        buf = C.create_string_buffer(70000)
+        n = self._lib.smc_bam_allele_key(self._h, int(ai), int(qpos), int(indel), buf, len(buf))
+        if n < 0:
+            raise BamError("allele key of alignment %d at %d: rc %d" % (ai, qpos, n))
+        return buf.value.decode()
+
+    def barcode_name(self, gid: int) -> str:
+        return self._lib.smc_bam_barcode_name(self._h, int(gid)).decode()
 
     def planes_run(self, chrom: str, lo: int, hi: int, max_reads: int, params, refseq: str, nthreads: int, fasta,
                    arena=None, arena_off: int = 0):

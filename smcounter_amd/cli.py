@@ -60,15 +60,25 @@ def call_shard(args, params: VcParams, loci, device: int):
     ref = fasta.FastaFile(args.refGenome)
     eng = Engine(device)
     output = []
-    if os.environ.get("SMC_BAM_DECODER", "native") == "python":       # readable decoder, same batches
+    decoder = os.environ.get("SMC_BAM_DECODER", "native")
+    # (one process per GPU: the ranks of a node share its cores for decoding)
+    # (LOCAL_WORLD_SIZE: WORLD_SIZE also counts the ranks of other nodes, which do not share these cores)
+    per_node = int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE", "1"))
+    nthreads = max(1, len(os.sched_getaffinity(0)) // max(1, per_node))
+    if decoder == "python":                                           # readable decoder, same batches
         batches = bamio.iter_pileup_batches(bamio.BamFile(args.bamFile), ref, loci, max_reads=args.batchReads)
-    else:
-        # (one process per GPU: the ranks of a node share its cores for decoding)
-        # (LOCAL_WORLD_SIZE: WORLD_SIZE also counts the ranks of other nodes, which do not share these cores)
-        per_node = int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE", "1"))
-        nthreads = max(1, len(os.sched_getaffinity(0)) // max(1, per_node))
+    elif os.environ.get("SMC_PLANES", "device") == "host":             # planes built by the host threads, then uploaded
         batches = bamio.iter_device_batches_native(args.bamFile, ref, loci, params, max_reads=args.batchReads,
                                                    nthreads=nthreads)
+    else:
+        # default: the host decodes alignments, the GPU builds the planes from them (k_build_planes) and they stay in HBM
+        from . import devplanes
+        batches = devplanes.iter_resident_batches(args.bamFile, ref, loci, params, eng, max_reads=args.batchReads,
+                                                  nthreads=nthreads)
+        for first, rb in batches:
+            output.extend(vc.vc_resident(rb, params, ref, eng))
+        eng.close()
+        return output
     for first, pb in _prefetch(batches):
         output.extend(vc.vc_batch(pb, params, ref, eng=eng))
     eng.close()

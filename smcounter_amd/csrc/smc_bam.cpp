@@ -104,6 +104,9 @@ struct Bam {
     // last smc_bam_planes result (keys / n_keys shared with the pileup result)
     std::vector<uint32_t> p_umi_start;
     std::string ds_info;               // loci over the barcode cap: "<locus>\t<u>:<barcode>\t...\n", barcodes by first included read
+    // last smc_bam_alignments result: the run's alignments (views into rec_data) and its barcode texts by run-wide id
+    std::vector<Aln> d_reads;
+    std::vector<std::string> d_bc_names;
 
     bool load_block(uint64_t coff) {
         if (fseeko(fh, (off_t)coff, SEEK_SET) != 0) return false;
@@ -833,6 +836,107 @@ void smc_bam_planes_copy(void* h, uint32_t* umi_start, int32_t* n_keys, char* ke
     memcpy(umi_start, b.p_umi_start.data(), 4 * b.p_umi_start.size());
     memcpy(n_keys, b.n_keys.data(), 4 * b.n_keys.size());
     memcpy(keys, b.keys.data(), b.keys.size());
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Device plane builder, host half: what the GPU needs of a run's alignments, as a structure of arrays (decode only - one
+// entry per ALIGNMENT; everything per pileup read - which reads cover which locus, query position, allele, quality,
+// flags, read class, barcode / fragment ids by first appearance, the barcode-major order - is done by k_build_planes).
+//   aln[n_aln]   smc_dev_aln (36 B): position, end, CIGAR / sequence offsets, flags, MAPQ, run-wide barcode / read-name ids
+//   cig[n_cig]   the CIGAR words of those alignments; seq / qual[n_seq]: their bases (one ASCII letter each) and qualities
+//   loc[n_loci]  per locus: window [w0, w1) of alignments that can cover it, first padded slot, depth
+// status bits: 1 = an alignment has neither READ1 nor READ2 (pairOrder is carried over between pileup reads,
+// smCounter.py:359-362: that needs the sequential path), 2 = a field does not fit the packed record.
+// `alloc(ctx, n_aln, n_cig, n_seq, n_loci, out)` must fill out[0..4] with buffers for aln, cig, seq, qual, loc.
+// Returns pileup reads (unpadded) or < 0 as smc_bam_pileup.
+typedef void (*smc_aln_alloc)(void* ctx, int64_t n_aln, int64_t n_cig, int64_t n_seq, int64_t n_loci, void** out);
+int64_t smc_bam_alignments(void* h, const char* chrom, int64_t start0, int64_t end0, int64_t max_reads, double mismatch_thr,
+                           int nthreads, smc_aln_alloc alloc, void* alloc_ctx, int64_t* n_loci_done, int64_t* n_slots,
+                           int32_t* n_bc_out, int32_t* n_pair_out, int32_t* status) {
+    Bam& b = *(Bam*)h;
+    b.io_threads = nthreads;
+    *n_loci_done = *n_slots = 0; *status = 0;
+    b.d_reads.clear(); b.d_bc_names.clear();
+    int n_bc = 0, n_pair = 0;
+    { const int rc = collect_reads(b, chrom, start0, end0, b.d_reads, n_bc, n_pair, &b.d_bc_names); if (rc) return rc; }
+    const std::vector<Aln>& reads = b.d_reads;
+    const int64_t span = end0 - start0;
+    std::vector<int64_t> cov((size_t)span + 1, 0);
+    for (const Aln& a : reads) {
+        const int64_t lo = std::max<int64_t>(a.pos, start0), hi = std::min<int64_t>(a.end, end0);
+        if (lo < hi) { ++cov[(size_t)(lo - start0)]; --cov[(size_t)(hi - start0)]; }
+    }
+    int64_t nl = 0, total = 0, run = 0, slots = 0;
+    std::vector<uint32_t> l_off, l_n;
+    for (int64_t k = 0; k < span; ++k) {
+        run += cov[(size_t)k];
+        total += run;
+        l_off.push_back((uint32_t)slots); l_n.push_back((uint32_t)run);
+        slots += (run + 3) / 4 * 4;
+        ++nl;
+        if (total >= max_reads) break;
+    }
+    int64_t n_cig = 0, n_seq = 0;
+    for (const Aln& a : reads) { n_cig += a.cigar.n; n_seq += a.l_seq; }
+    void* bufs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    alloc(alloc_ctx, (int64_t)reads.size(), n_cig, n_seq, nl, bufs);
+    smc_dev_aln* pa = (smc_dev_aln*)bufs[0]; uint32_t* pc = (uint32_t*)bufs[1];
+    uint8_t* ps = (uint8_t*)bufs[2]; uint8_t* pq = (uint8_t*)bufs[3]; smc_dev_locus* pl = (smc_dev_locus*)bufs[4];
+    if ((!reads.empty() && (!pa || !pc || !ps || !pq)) || (nl && !pl)) { b.err = "smc_bam_alignments: allocation callback returned no memory"; return -9; }
+    size_t oc = 0, os = 0;
+    int st = 0;
+    for (size_t i = 0; i < reads.size(); ++i) {
+        const Aln& a = reads[i];
+        smc_dev_aln& d = pa[i];
+        d.pos = a.pos; d.end = a.end;
+        d.cig_off = (uint32_t)oc; d.seq_off = (uint32_t)os;
+        if (a.cigar.n > 65535 || a.left_sp > 65535 || a.qalen > 65535 || a.l_seq > 65535) st |= 2;
+        d.n_cig = (uint16_t)a.cigar.n;
+        const int64_t mism = std::max<int64_t>(0, (int64_t)a.nm - (int64_t)a.n_ind);
+        const double mm100 = a.l_seq > 0 ? 100.0 * (double)mism / (double)a.l_seq : 0.0;     // smCounter.py:352-356
+        if (!(a.oflag & 3)) st |= 1;
+        d.oflag = (uint8_t)((a.oflag & 7) | (mm100 <= mismatch_thr ? SMC_DA_MMOK : 0));
+        d.mapq = a.mapq;
+        d.left_sp = (uint16_t)a.left_sp; d.qalen = (uint16_t)a.qalen;
+        d.l_seq = (uint16_t)a.l_seq; d.pad = 0;
+        d.bc_gid = (uint32_t)a.bc_gid; d.pair_gid = (uint32_t)a.pair_gid;
+        for (uint32_t c : a.cigar) pc[oc++] = c;
+        for (uint32_t k = 0; k < a.l_seq; ++k) { ps[os] = (uint8_t)a.seq[k]; pq[os] = a.qual[k]; ++os; }
+    }
+    // candidate window of every locus: [first alignment that ends behind it ... first alignment that starts behind it)
+    size_t w0 = 0, w1 = 0;
+    for (int64_t l = 0; l < nl; ++l) {
+        const int64_t p0 = start0 + l;
+        while (w0 < reads.size() && reads[w0].end <= p0) ++w0;
+        while (w1 < reads.size() && reads[w1].pos <= p0) ++w1;
+        pl[l].w0 = (uint32_t)w0; pl[l].w1 = (uint32_t)std::max(w0, w1);
+        pl[l].slot_off = l_off[(size_t)l]; pl[l].n = l_n[(size_t)l];
+    }
+    *n_loci_done = nl; *n_slots = slots; *n_bc_out = n_bc; *n_pair_out = n_pair; *status = st;
+    return total;
+}
+
+// key text of an allele the device builder saw first on alignment `ai` of the last smc_bam_alignments at query position
+// qpos with `indel` (k_build_planes reports that triple for every allele beyond the six fixed ones): "INS|b|b<ins>",
+// "D<len>|b" (the caller appends the deleted reference bases, smCounter.py:392-396) or the letter itself.
+int smc_bam_allele_key(void* h, int64_t ai, int32_t qpos, int32_t indel, char* out, int cap) {
+    Bam& b = *(Bam*)h;
+    if (ai < 0 || (size_t)ai >= b.d_reads.size() || qpos < 0) return -1;
+    const Aln& a = b.d_reads[(size_t)ai];
+    if ((uint32_t)qpos >= a.l_seq) return -1;
+    const char site = a.seq[(size_t)qpos];
+    std::string key;
+    if (indel > 0) key = std::string("INS|") + site + "|" + site + a.seq.substr((size_t)qpos + 1, (size_t)indel);
+    else if (indel < 0) key = "D" + std::to_string(-indel) + "|" + site;
+    else key = std::string(1, site);
+    if ((int)key.size() + 1 > cap) return -2;
+    memcpy(out, key.c_str(), key.size() + 1);
+    return (int)key.size();
+}
+// text of run-wide barcode id `gid` of the last smc_bam_alignments (for the reference's down-sampling, :496-498)
+const char* smc_bam_barcode_name(void* h, int32_t gid) {
+    Bam& b = *(Bam*)h;
+    return (gid >= 0 && (size_t)gid < b.d_bc_names.size()) ? b.d_bc_names[(size_t)gid].c_str() : "";
 }
 
 }  // extern "C"

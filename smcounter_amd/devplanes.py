@@ -1,0 +1,181 @@
+"""Device-resident batches: BAM -> alignments (host decode) -> planes built ON THE GPU (smc_build_planes) -> hot path.
+
+The per-pileup-read half of the reference's feature extraction and barcode bookkeeping (smCounter.py:316-366, :371-452,
+:462-471) runs in csrc/k_build_planes.inc; the host keeps the per-alignment half (csrc/smc_bam.cpp: smc_bam_alignments)
+and whatever needs strings: the texts of indel alleles, the reference's down-sampling on barcode texts (:496-498, py2
+semantics).  A run the device path does not take (a locus deeper than smc_build_max_depth(), an alignment with neither
+READ1 nor READ2, an overflow the kernel reports) is built by the host builder (smc_bam_planes) and uploaded into the same
+device arrays - same planes either way (tests/test_gpu_parity.py compares them byte for byte).
+"""
+from __future__ import annotations
+
+import ctypes
+import dataclasses
+import os
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib, abi, bamio
+from .features import LF_SAMPLED, LOCUS_DTYPE, USTART_DROPPED
+from .pileup import BASE_ALLELES
+
+
+@dataclasses.dataclass
+class ResidentBatch:
+    """A batch whose planes live in HBM (torch tensors); the descriptors and what row formatting needs are on the host."""
+    planes: list               # [meta, umi, frag, dist, umi_start] int32 CUDA tensors
+    loci: np.ndarray           # LOCUS_DTYPE[n_loci] (host copy; offsets are batch-relative)
+    chrom: List[str]
+    pos: np.ndarray
+    ref: List[str]
+    alleles: List[List[str]]
+    n_device_runs: int = 0     # runs built by k_build_planes / by the host builder (fallback)
+    n_host_runs: int = 0
+
+    @property
+    def n_loci(self) -> int:
+        return len(self.loci)
+
+    def to_host(self):
+        """-> features.DeviceBatch with the planes copied back (tests, the CPU restatement)."""
+        from .features import DeviceBatch
+        m, u, f, d, us = (t.cpu().numpy().view(np.uint32) for t in self.planes)
+        return DeviceBatch(loci=self.loci.copy(), meta=m, umi=u, frag=f, dist=d, umi_start=us, chrom=list(self.chrom),
+                           pos=self.pos.copy(), ref=list(self.ref), alleles=[list(t) for t in self.alleles])
+
+
+def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], params, eng, max_reads: int = 4_000_000,
+                          nthreads: int = 0, force_host: bool = False):
+    """BAM -> `ResidentBatch` chunks: same loci per chunk as bamio.iter_device_batches_native, planes built on the GPU."""
+    import torch
+    L = eng.L
+    dev = torch.device("cuda", eng.device)
+    bam = bamio.NativeBam(path)
+    nthreads = nthreads or len(os.sched_getaffinity(0))
+    max_depth = L.smc_build_max_depth()
+    cp = abi.c_params(params)
+    st = torch.cuda.current_stream(eng.device)
+    i, n = 0, len(loci)
+    cap = max_reads + (max_reads >> 3) + 65536
+    while i < n:
+        first = i
+        planes = [torch.empty(cap, dtype=torch.int32, device=dev) for _ in range(4)]
+        uaux = [torch.empty(cap + 8192, dtype=torch.int32, device=dev) for _ in range(3)]      # umi_start, u_gid, u_finc
+        LC, chroms, poss, refs, tables = [], [], [], [], []
+        total = slots = n_loc = 0
+        n_dev = n_host = 0
+        while i < n and total < max_reads:
+            chrom = loci[i][0]
+            j = i
+            while j + 1 < n and loci[j + 1][0] == chrom and int(loci[j + 1][1]) == int(loci[j][1]) + 1 and j + 1 - i < 4096:
+                j += 1
+            lo, hi = int(loci[i][1]) - 1, int(loci[j][1])
+            run_ref = fasta.fetch(chrom, lo, hi).upper()
+            umi_base = slots + n_loc
+            done = None
+            if not force_host:
+                done = _device_run(bam, L, eng, cp, params, chrom, lo, hi, max_reads - total, nthreads, fasta, run_ref, planes, uaux,
+                                   slots, umi_base, cap, max_depth, dev, st)
+            if done is None:
+                # host builder (the run is not one the device path takes): same planes, uploaded
+                nl, hp, ustart, lc, tb = bam.planes_run(chrom, lo, hi, max_reads - total, params, run_ref, nthreads, fasta)
+                ns = len(hp[0])
+                if slots + ns > cap or umi_base + len(ustart) > cap + 8192:
+                    raise bamio.BamError("run of %d read slots does not fit the device arena" % ns)
+                for k in range(4):
+                    planes[k][slots:slots + ns].copy_(torch.from_numpy(hp[k].view(np.int32)))
+                uaux[0][umi_base:umi_base + len(ustart)].copy_(torch.from_numpy(ustart.view(np.int32)))
+                lc = lc.copy()
+                lc["read_off4"] += slots // 4
+                lc["umi_off"] += umi_base
+                n_host += 1
+            else:
+                nl, ns, lc, tb = done
+                n_dev += 1
+            LC.append(lc)
+            slots += ns
+            n_loc += nl
+            total += int(lc["n_reads"].sum())
+            chroms += [chrom] * nl
+            poss += list(range(lo + 1, lo + 1 + nl))
+            refs += [run_ref[k:k + 1] for k in range(nl)]
+            tables += tb
+            i += nl
+        lc_all = LC[0] if len(LC) == 1 else np.concatenate(LC)
+        yield first, ResidentBatch(planes=[planes[0][:slots], planes[1][:slots], planes[2][:slots], planes[3][:slots],
+                                           uaux[0][:slots + n_loc + 1]],
+                                   loci=lc_all, chrom=chroms, pos=np.array(poss, np.int64), ref=refs, alleles=tables,
+                                   n_device_runs=n_dev, n_host_runs=n_host)
+    bam.close()
+
+
+def _device_run(bam, L, eng, cp, params, chrom, lo, hi, max_reads, nthreads, fasta, run_ref, planes, uaux, slot_base, umi_base,
+                cap, max_depth, dev, st):
+    """One run through smc_bam_alignments + smc_build_planes.  -> (n loci, slots, descriptors, allele tables) or None
+    when the run has to take the host builder."""
+    import torch
+    A = bam.alignments_run(chrom, lo, hi, max_reads, params, nthreads)
+    nl, ns = A["nl"], A["n_slots"]
+    if nl == 0:
+        return 0, 0, np.zeros(0, LOCUS_DTYPE), []
+    if A["status"] != 0 or (len(A["loc"]) and int(A["loc"]["n"].max()) > max_depth) or slot_base + ns > cap or \
+            umi_base + ns + nl + 1 > cap + 8192:
+        return None
+    up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev, non_blocking=False)
+    d_aln = up(A["aln"].view(np.uint8) if len(A["aln"]) else np.zeros(36, np.uint8), np.uint8)
+    d_cig, d_seq, d_qual = up(A["cig"], np.int32), up(A["seq"], np.uint8), up(A["qual"], np.uint8)
+    d_loc = up(A["loc"].view(np.uint8), np.uint8)
+    d_ref = up(np.frombuffer(run_ref[:nl].encode().ljust(nl, b"\0"), np.uint8).copy(), np.uint8)
+    d_loci = torch.empty(nl * LOCUS_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    xcap = 4 * nl + 4096
+    d_x = torch.empty(5 * xcap, dtype=torch.int32, device=dev)
+    d_cnt = torch.zeros(2, dtype=torch.int32, device=dev)
+    bi = abi.SmcBuildIn(d_aln.data_ptr(), d_cig.data_ptr(), d_seq.data_ptr(), d_qual.data_ptr(), d_loc.data_ptr(), d_ref.data_ptr(),
+                        lo, nl, A["n_bc"], A["n_pair"])
+    _lib.check(L.smc_build_planes(eng.ctx, ctypes.byref(cp), ctypes.byref(bi), slot_base, umi_base, planes[0].data_ptr(),
+                                  planes[1].data_ptr(), planes[2].data_ptr(), planes[3].data_ptr(), uaux[0].data_ptr(),
+                                  uaux[1].data_ptr(), uaux[2].data_ptr(), d_loci.data_ptr(), d_x.data_ptr(), xcap,
+                                  d_cnt.data_ptr(), ctypes.c_void_p(st.cuda_stream)), "smc_build_planes")
+    cnt = d_cnt.cpu().numpy().view(np.uint32)
+    if int(cnt[1]) != 0 or int(cnt[0]) > xcap:
+        if int(cnt[1]) & 4:
+            from .features import PileupError
+            raise PileupError("base quality > 126 at %s:%d-%d" % (chrom, lo + 1, lo + nl))
+        return None
+    lc = d_loci.cpu().numpy().view(LOCUS_DTYPE).copy()
+    # allele tables: the six fixed keys + what the kernel met, in the order it numbered them
+    tables = [list(BASE_ALLELES) for _ in range(nl)]
+    nx = int(cnt[0])
+    if nx:
+        xl = d_x[:5 * nx].cpu().numpy().view(np.uint32).reshape(nx, 5)
+        xl = xl[np.lexsort((xl[:, 1], xl[:, 0]))]
+        for l, aid, ai, qpos, indel in xl.tolist():
+            key = bam.allele_key(ai, qpos, np.int32(np.uint32(indel)))
+            if key[0] == "D" and len(key) > 1:        # "D<len>|<site>" -> DEL|site+deleted|site (smCounter.py:392-396)
+                ln, site = key[1:].split("|")
+                pos1 = lo + l + 1
+                key = "DEL|" + site + fasta.fetch(chrom, pos1, pos1 + int(ln)).upper() + "|" + site
+            assert aid == len(tables[l]), (l, aid, len(tables[l]))
+            tables[l].append(key)
+    # the reference's down-sampling (smCounter.py:496-498) on loci over the barcode cap: barcode texts by first included read
+    over = np.nonzero(lc["n_umi"] > params.ds)[0] if params.ds > 0 else []
+    if len(over):
+        from .py2compat import py2_downsample_barcodes
+        for l in over.tolist():
+            o, nu = int(lc["umi_off"][l]), int(lc["n_umi"][l])
+            us = uaux[0][o:o + nu].cpu().numpy().view(np.uint32).copy()
+            gid = uaux[1][o:o + nu].cpu().numpy().view(np.uint32)
+            finc = uaux[2][o:o + nu].cpu().numpy().view(np.uint32)
+            keys = np.nonzero(finc != 0xFFFFFFFF)[0]
+            keys = keys[np.argsort(finc[keys], kind="stable")]
+            if len(keys) <= params.ds:
+                continue
+            names = [bam.barcode_name(int(gid[u])) for u in keys]
+            kept = set(py2_downsample_barcodes(str(lo + l + 1), names, params.ds))
+            for u, name in zip(keys.tolist(), names):
+                if name not in kept:
+                    us[u] |= USTART_DROPPED
+            uaux[0][o:o + nu].copy_(torch.from_numpy(us.view(np.int32)))
+            lc["flags"][l] |= LF_SAMPLED
+    return nl, ns, lc, tables

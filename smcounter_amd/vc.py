@@ -41,6 +41,28 @@ def vc_batch(pb, params: VcParams, refprov, eng: Optional[_engine.Engine] = None
     return text
 
 
+def vc_resident(rb, params: VcParams, refprov, eng: _engine.Engine) -> List[str]:
+    """`vc_batch` for a batch whose planes are already in HBM (devplanes.ResidentBatch: built there by smc_build_planes):
+    plan, kernels, rows back, strings - no plane ever crosses PCIe."""
+    plan = eng.make_plan(rb.loci)
+    try:
+        out_rows = plan.download(plan.run(rb.planes, params))
+    finally:
+        plan.close()
+    text = []
+    try:
+        return rows.format_rows(out_rows, rb, params, refprov)
+    except Exception:
+        pass
+    for l in range(rb.n_loci):                       # (a failing locus: find it, the reference's failure convention)
+        try:
+            text.append(rows.format_row(out_rows[l], rb.chrom[l], rb.pos[l], rb.ref[l], rb.alleles[l], params, refprov))
+        except Exception:
+            print("Exception thrown in vc() function at genome location:", rb.chrom[l], int(rb.pos[l]))
+            text.append(EXC_PREFIX + "\n" + traceback.format_exc())
+    return text
+
+
 def raise_on_exception(output: List[str], loc_list) -> None:
     """main()'s scan for worker failures (smCounter.py:689-694)."""
     for line, loc in zip(output, loc_list):

@@ -1,0 +1,112 @@
+"""The device plane builder (k_build_planes, through smc_bam_alignments + smc_build_planes) against the host builder
+(smc_bam_planes): the same planes byte for byte, the same descriptors, barcode boundaries, sampling marks and allele tables,
+on random BAMs (CIGARs with S/M/I/D/N, two chromosomes, odd read names), the variant fixture, and under a barcode cap that
+triggers the reference's down-sampling; then the whole command line with planes built either way."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from smcounter_amd import abi, bamio, fasta, features
+from smcounter_amd.params import VcParams
+
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+pytestmark = pytest.mark.gpu
+
+
+def _same_batch(rb, hb):
+    """ResidentBatch (device-built, copied back) vs DeviceBatch (host-built)."""
+    db = rb.to_host()
+    assert db.n_loci == hb.n_loci
+    for f in ("n_reads", "n_umi", "n_frag", "ref_allele", "n_alleles", "flags", "snp_mask", "read_off4"):
+        assert np.array_equal(db.loci[f], hb.loci[f]), f
+    for k in ("meta", "umi", "frag", "dist"):
+        x, y = getattr(db, k), getattr(hb, k)
+        assert x.dtype == y.dtype and np.array_equal(x, y), k
+    for l in range(db.n_loci):
+        o1, o2, nu = int(db.loci["umi_off"][l]), int(hb.loci["umi_off"][l]), int(hb.loci["n_umi"][l])
+        assert np.array_equal(db.umi_start[o1:o1 + nu + 1], hb.umi_start[o2:o2 + nu + 1]), l
+    assert db.chrom == hb.chrom and db.ref == hb.ref and np.array_equal(db.pos, hb.pos)
+    assert db.alleles == hb.alleles
+
+
+@pytest.mark.parametrize("mt_depth", [1000, 4])          # 4 -> ds = 8 < 25 barcodes: the py2 down-sampling marks
+@pytest.mark.parametrize("max_reads", [5000, 2_000_000])
+def test_device_built_planes_equal_host_built(engine0, tmp_path, max_reads, mt_depth):
+    import test_bamio
+    from smcounter_amd import devplanes
+    bam, fa_path, loci = test_bamio._random_bam(tmp_path, 23, True)
+    fa = fasta.FastaFile(fa_path)
+    P = VcParams(mtDepth=mt_depth, rpb=3.0, hpLen=8, minBQ=15, minMQ=20, mismatchThr=8.0)
+    host = list(bamio.iter_device_batches_native(bam, fa, loci, P, max_reads=max_reads, nthreads=3))
+    dev = list(devplanes.iter_resident_batches(bam, fa, loci, P, engine0, max_reads=max_reads, nthreads=3))
+    assert len(host) == len(dev) >= 1
+    n_dev = 0
+    for (f1, hb), (f2, rb) in zip(host, dev):
+        assert f1 == f2
+        _same_batch(rb, hb)
+        n_dev += rb.n_device_runs
+    assert n_dev > 0                                        # (the device path really ran)
+    if mt_depth == 4:
+        assert any((hb.loci["flags"] & features.LF_SAMPLED).any() for _, hb in host)
+        assert any((np.concatenate([hb.umi_start for _, hb in host]) >> 31).any() for _ in (0,))
+
+
+def test_device_planes_on_the_variant_fixture_and_rows(engine0, tmp_path):
+    """bam_fixture (planted variant, indels, soft clips): planes equal, and the rows of the device-built batch equal the
+    rows of the host-built one through the same kernels."""
+    import bam_fixture
+    from smcounter_amd import devplanes, rows, vc
+    case = bam_fixture.make_case(str(tmp_path))
+    fa = fasta.FastaFile(case["fasta"])
+    from smcounter_amd import bedops
+    loci = bedops.expand_loci(case["bed"])
+    P = VcParams(mtDepth=12, rpb=3.0, hpLen=8)
+    host = list(bamio.iter_device_batches_native(case["bam"], fa, loci, P))
+    dev = list(devplanes.iter_resident_batches(case["bam"], fa, loci, P, engine0))
+    for (_, hb), (_, rb) in zip(host, dev):
+        _same_batch(rb, hb)
+        assert rb.n_device_runs >= 1
+        got = vc.vc_resident(rb, P, fa, engine0)
+        want = rows.format_rows(engine0.call_batch_host(hb, P), hb, P, fa)
+        assert got == want
+    assert any(len(t) > 6 for _, hb in host for t in hb.alleles)      # indel alleles went through the extras list
+
+
+def test_runs_the_device_path_does_not_take_fall_back(engine0, tmp_path):
+    """An alignment with neither READ1 nor READ2 (the reference's pairOrder is then carried over between pileup reads,
+    smCounter.py:359-362) sends its run to the host builder; the batch is the same."""
+    from smcounter_amd import devplanes
+    ref = "ACGTTGCAAC" * 30
+    fa_path = str(tmp_path / "d.fa")
+    open(fa_path, "w").write(">chrD\n" + ref + "\n")
+    recs = [dict(tid=0, pos=10 + (i % 7), qname="r%d:x:BC%d:y" % (i // 2, i % 5), flag=(0x41 if i % 2 == 0 else 0x91) if i != 9 else 0x10,
+                 mapq=60, cigar=[(0, 40)], seq=ref[10 + (i % 7):50 + (i % 7)], qual=[30] * 40, nm=0) for i in range(40)]
+    recs.sort(key=lambda r: r["pos"])
+    bam = str(tmp_path / "d.bam")
+    bamio.write_bam(bam, [("chrD", len(ref))], recs)
+    bamio.write_bai(bam)
+    fa = fasta.FastaFile(fa_path)
+    loci = [("chrD", str(p)) for p in range(15, 45)]
+    P = VcParams(mtDepth=100, rpb=2.0)
+    host = list(bamio.iter_device_batches_native(bam, fa, loci, P))
+    dev = list(devplanes.iter_resident_batches(bam, fa, loci, P, engine0))
+    for (_, hb), (_, rb) in zip(host, dev):
+        _same_batch(rb, hb)
+        assert rb.n_device_runs == 0 and rb.n_host_runs >= 1
+
+
+def test_cli_device_and_host_planes_write_the_same_files(tmp_path, monkeypatch):
+    import bam_fixture
+    from smcounter_amd import cli
+    case = bam_fixture.make_case(str(tmp_path))
+    outs = []
+    for mode in ("device", "host"):
+        monkeypatch.setenv("SMC_PLANES", mode)
+        prefix = str(tmp_path / mode)
+        cli.main(dict(outPrefix=prefix, bamFile=case["bam"], bedTarget=case["bed"], mtDepth=12, rpb=3.0, hpLen=8,
+                      refGenome=case["fasta"], threshold=10))
+        outs.append(open(prefix + ".smCounter.all.txt").read())
+    assert outs[0] == outs[1] and outs[0].count("\n") > 10
