@@ -332,6 +332,14 @@ int smc_build_planes(smc_ctx* ctx, const smc_params* params, const smc_build_in*
                      uint32_t* meta, uint32_t* umi, uint32_t* frag, uint32_t* dist, uint32_t* umi_start, uint32_t* u_gid,
                      uint32_t* u_finc, smc_locus* loci, uint32_t* xlist, uint32_t xcap, uint32_t* counters, void* stream);
 
+/* Device memory for callers without a GPU runtime of their own (the Python command line uses these instead of importing
+ * PyTorch: about a second of start-up): allocation, synchronous copies, device synchronisation. */
+int smc_mem_alloc(smc_ctx* ctx, int64_t bytes, void** out);
+void smc_mem_free(smc_ctx* ctx, void* p);
+int smc_mem_h2d(smc_ctx* ctx, void* dst_device, const void* src_host, int64_t bytes);
+int smc_mem_d2h(smc_ctx* ctx, void* dst_host, const void* src_device, int64_t bytes);
+int smc_device_sync(smc_ctx* ctx);
+
 /* HIP-event timing helpers so a host language without HIP bindings can time the stream the
  * kernels run on. */
 int smc_event_create(void** ev);

@@ -14,7 +14,8 @@ SYMBOLS = ("smc_abi_version", "smc_last_error", "smc_row_size", "smc_locus_size"
            "smc_create", "smc_destroy", "smc_plan_create", "smc_plan_destroy", "smc_plan_info",
            "smc_plan_run", "smc_plan_set_timing", "smc_plan_kernel_ms", "smc_call_batch_host", "smc_event_create", "smc_event_record",
            "smc_event_elapsed_ms", "smc_event_destroy", "smc_class_table", "smc_wire_row_size", "smc_pack_rows", "smc_unpack_rows",
-           "smc_build_planes", "smc_build_max_depth")
+           "smc_build_planes", "smc_build_max_depth", "smc_mem_alloc", "smc_mem_free", "smc_mem_h2d", "smc_mem_d2h",
+           "smc_device_sync")
 
 
 class SmcError(RuntimeError):
@@ -68,6 +69,12 @@ def load(with_torch: bool = True):
     L.smc_wire_row_size.restype = ctypes.c_int
     L.smc_pack_rows.argtypes = [vp, vp, i64, vp, vp]
     L.smc_unpack_rows.argtypes = [vp, i64, vp]
+    L.smc_mem_alloc.argtypes = [vp, i64, ctypes.POINTER(vp)]
+    L.smc_mem_free.argtypes = [vp, vp]
+    L.smc_mem_free.restype = None
+    L.smc_mem_h2d.argtypes = [vp, vp, vp, i64]
+    L.smc_mem_d2h.argtypes = [vp, vp, vp, i64]
+    L.smc_device_sync.argtypes = [vp]
     L.smc_build_max_depth.restype = ctypes.c_int
     L.smc_build_planes.argtypes = [vp, ctypes.POINTER(abi.SmcParams), ctypes.POINTER(abi.SmcBuildIn), ctypes.c_uint32,
                                    ctypes.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_uint32, vp, vp]

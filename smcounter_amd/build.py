@@ -64,7 +64,7 @@ def build_bam(force: bool = False) -> str:
     if force or not os.path.exists(BAM_LIB) or \
             max(os.path.getmtime(BAM_SRC), os.path.getmtime(hdr)) > os.path.getmtime(BAM_LIB):
         subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-pthread",
-                               "-I" + os.path.join(ROOT, "include"), "-o", BAM_LIB, BAM_SRC, "-lz"])
+                               "-I" + os.path.join(ROOT, "include"), "-o", BAM_LIB, BAM_SRC, "-lz", "-ldl"])
     return BAM_LIB
 
 

@@ -73,7 +73,8 @@ def call_shard(args, params: VcParams, loci, device: int):
     else:
         # default: the host decodes alignments, the GPU builds the planes from them (k_build_planes) and they stay in HBM
         from . import devplanes
-        batches = devplanes.iter_resident_batches(args.bamFile, ref, loci, params, eng, max_reads=args.batchReads,
+        # (a batch only lives in HBM here - 16 B per read - so it can be eight times the host-built default)
+        batches = devplanes.iter_resident_batches(args.bamFile, ref, loci, params, eng, max_reads=8 * args.batchReads,
                                                   nthreads=nthreads)
         for first, rb in batches:
             output.extend(vc.vc_resident(rb, params, ref, eng))

@@ -206,6 +206,26 @@ void parse_body(const uint8_t* p, size_t r_size, Aln& a, int32_t& tid) {
     a.end = e;
 }
 
+// libdeflate, when the image has it (the shared object without its header: the three entry points are declared here),
+// inflates a BGZF block 2-3 x faster than zlib; zlib stays the fallback.
+#include <dlfcn.h>
+struct Libdeflate {
+    void* (*alloc)(void) = nullptr;
+    int (*decompress)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;
+    void (*release)(void*) = nullptr;
+    Libdeflate() {
+        if (getenv("SMC_BAM_ZLIB")) return;
+        void* h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        alloc = (void* (*)(void))dlsym(h, "libdeflate_alloc_decompressor");
+        decompress = (int (*)(void*, const void*, size_t, void*, size_t, size_t*))dlsym(h, "libdeflate_deflate_decompress");
+        release = (void (*)(void*))dlsym(h, "libdeflate_free_decompressor");
+        if (!alloc || !decompress || !release) alloc = nullptr;
+    }
+    bool ok() const { return alloc != nullptr; }
+};
+static const Libdeflate g_ld;
+
 // Record stream over consecutive BGZF blocks starting at a virtual offset: blocks are read from the file in
 // batches and inflated by `nthreads` threads (each block is an independent deflate stream), records are then
 // parsed in place.
@@ -256,9 +276,15 @@ struct BlockStream {
         data.resize(base + total);
         std::atomic<int> bad(0), next(0);
         auto work = [&]() {
+            void* ld = g_ld.ok() ? g_ld.alloc() : nullptr;
             for (int i = next.fetch_add(1); i < (int)raws.size(); i = next.fetch_add(1)) {
                 Raw& r = raws[(size_t)i];
                 if (!r.isize) continue;
+                if (ld) {
+                    size_t got = 0;
+                    if (g_ld.decompress(ld, r.comp.data() + r.c0, r.clen, data.data() + base + r.out_off, r.isize, &got) != 0 || got != r.isize) bad = 1;
+                    continue;
+                }
                 z_stream zs;
                 memset(&zs, 0, sizeof zs);
                 if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; continue; }
@@ -267,6 +293,7 @@ struct BlockStream {
                 if (inflate(&zs, Z_FINISH) != Z_STREAM_END) bad = 1;
                 inflateEnd(&zs);
             }
+            if (ld) g_ld.release(ld);
         };
         const int T = std::min<int>(nthreads, ((int)raws.size() + 3) / 4);   // >= 4 blocks (~1 ms) per thread started
         if (T <= 1) work();
@@ -303,7 +330,6 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::
                   std::vector<std::string>* bc_names = nullptr) {
     int tid = -1;
     for (size_t i = 0; i < b.ref_names.size(); ++i) if (b.ref_names[i] == chrom) tid = (int)i;
-    std::unordered_map<std::string, int> bc_ids, pair_ids;
     if (tid >= 0) {
         uint64_t voff = b.first_record;
         if ((size_t)tid < b.lin.size() && !b.lin[(size_t)tid].empty()) {
@@ -326,6 +352,7 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::
                 if (iv[w]) { stop_hint = iv[w] >> 16; break; }
         }
         // 1. inflate (threads) and find the record boundaries up to the first alignment starting at or after end0
+        const auto tc0 = std::chrono::steady_clock::now();
         BlockStream bs(b, voff, b.io_threads, true, stop_hint);
         std::vector<std::pair<size_t, size_t>> recs;    // (offset of the body in bs.data, size)
         for (;;) {
@@ -342,6 +369,7 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::
         b.rec_data = std::move(bs.data);
         const uint8_t* const rec_base = b.rec_data.data();
         // 2. parse them (threads), 3. filter and intern barcode / read ids in file order
+        const auto tc1 = std::chrono::steady_clock::now();
         std::vector<Aln> parsed(recs.size());
         {
             const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)b.io_threads, recs.size() / 2048 + 1));
@@ -382,13 +410,14 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::
                 for (auto& x : th) x.join();
             }
         }
+        const auto tc2 = std::chrono::steady_clock::now();
         bool have_first = false, have_end = false;
         b.cur_end = -1; b.cur_voff_end = 0;
-        // interning by 64-bit hash; a hit is confirmed against the first read that produced the id
-        std::unordered_map<uint64_t, int> hb, hp;
-        std::vector<size_t> bc_rep, pair_rep;           // index into `reads` of the id's first read
+        // 3a. which records the run keeps, the cursor checkpoints and the first malformed record - in file order (cheap)
+        std::vector<uint8_t> keep(parsed.size(), 0);
+        size_t n_keep = 0;
         for (size_t pi = 0; pi < parsed.size(); ++pi) {
-            Aln& a = parsed[pi];
+            const Aln& a = parsed[pi];
             if ((a.flag & 4) || a.cigar.empty()) continue;
             if (a.end <= start0) continue;
             if (!have_first) {                         // (its block_size word sits 4 bytes before the body)
@@ -400,44 +429,102 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::
                 b.cur_end = end0; b.cur_voff_end = bs.voffset_of(recs[pi].first - 4);
             }
             // qname -> barcode / read id (smCounter.py:320-325): <readid...>:<UMI>:<x>
-            const std::string_view qn = a.qname;
-            if (a.c2 < 0) { b.err = "read name '" + std::string(qn) + "' has fewer than 3 ':' fields"; return -3; }
-            if (a.l_seq == 0) { b.err = "alignment " + std::string(qn) + " has no sequence"; return -4; }
-            const size_t c1 = (size_t)a.c1, c2 = (size_t)a.c2;
-            auto same_bc = [&](const Aln& o) {
-                return (size_t)(o.c1 - o.c2) == c1 - c2 && memcmp(o.qname.data() + o.c2 + 1, qn.data() + c2 + 1, c1 - c2 - 1) == 0;
-            };
-            {
-                auto it = hb.find(a.h_bc);
-                if (it != hb.end() && same_bc(reads[bc_rep[(size_t)it->second]])) a.bc_gid = it->second;
-                else if (it == hb.end()) { a.bc_gid = (int)bc_rep.size(); hb.emplace(a.h_bc, a.bc_gid); bc_rep.push_back(reads.size()); bc_ids.emplace(std::string(qn.substr(c2 + 1, c1 - c2 - 1)), a.bc_gid); }
-                else {                                   // hash collision: fall back to the string map
-                    auto r = bc_ids.emplace(std::string(qn.substr(c2 + 1, c1 - c2 - 1)), (int)bc_rep.size());
-                    if (r.second) bc_rep.push_back(reads.size());
-                    a.bc_gid = r.first->second;
-                }
-            }
-            {
-                auto it = hp.find(a.h_pair);
-                const bool hit = it != hp.end() && [&] {
-                    const Aln& o = reads[pair_rep[(size_t)it->second]];
-                    return o.c2 == a.c2 && same_bc(o) && memcmp(o.qname.data(), qn.data(), c2) == 0;
-                }();
-                if (hit) a.pair_gid = it->second;
-                else if (it == hp.end()) { a.pair_gid = (int)pair_rep.size(); hp.emplace(a.h_pair, a.pair_gid); pair_rep.push_back(reads.size()); }
-                else {
-                    auto r = pair_ids.emplace(std::string(qn.substr(c2 + 1, c1 - c2 - 1)) + "\x01" + std::string(qn.substr(0, c2)), (int)pair_rep.size());
-                    if (r.second) pair_rep.push_back(reads.size());
-                    a.pair_gid = r.first->second;
-                }
-            }
-            reads.push_back(std::move(a));
+            if (a.c2 < 0) { b.err = "read name '" + std::string(a.qname) + "' has fewer than 3 ':' fields"; return -3; }
+            if (a.l_seq == 0) { b.err = "alignment " + std::string(a.qname) + " has no sequence"; return -4; }
+            keep[pi] = 1; ++n_keep;
         }
-        n_bc = (int)bc_rep.size(); n_pair = (int)pair_rep.size();
+        // 3b. run-wide barcode / read-name ids by 64-bit hash, a hit confirmed against the first record that produced the id
+        // (memcmp) and a colliding hash resolved through a string map.  Sharded by hash over the threads: a shard owns its
+        // hashes, so ids are dense and exact whatever the thread count (they number DISTINCT strings; nothing downstream
+        // depends on their order: first-appearance numbering happens per locus).
+        int SH = 1;
+        while (SH < 16 && SH * 2 <= b.io_threads && (size_t)SH * 8192 < n_keep) SH *= 2;
+        if (const char* e = getenv("SMC_BAM_SHARDS")) { SH = 1; while (SH < 16 && SH * 2 <= atoi(e)) SH *= 2; }   // (tests)
+        struct Shard {
+            std::unordered_map<uint64_t, int> hb, hp;
+            std::vector<size_t> bc_rep, pair_rep;                       // index into `parsed` of the id's first record
+            std::unordered_map<std::string, int> bc_str, pair_str;     // only for colliding hashes
+        };
+        std::vector<Shard> shards((size_t)SH);
+        auto bc_equal = [&](const Aln& o, const Aln& a) {
+            return (o.c1 - o.c2) == (a.c1 - a.c2) && memcmp(o.qname.data() + o.c2 + 1, a.qname.data() + a.c2 + 1, (size_t)(a.c1 - a.c2 - 1)) == 0;
+        };
+        auto intern = [&](int t) {
+            Shard& S = shards[(size_t)t];
+            const uint64_t msk = (uint64_t)SH - 1;
+            for (size_t pi = 0; pi < parsed.size(); ++pi) {
+                if (!keep[pi]) continue;
+                Aln& a = parsed[pi];
+                const std::string_view qn = a.qname;
+                const size_t c1 = (size_t)a.c1, c2 = (size_t)a.c2;
+                if (((a.h_bc >> 20) & msk) == (uint64_t)t) {
+                    auto it = S.hb.find(a.h_bc);
+                    if (it != S.hb.end() && bc_equal(parsed[S.bc_rep[(size_t)it->second]], a)) a.bc_gid = it->second;
+                    else if (it == S.hb.end()) { a.bc_gid = (int)S.bc_rep.size(); S.hb.emplace(a.h_bc, a.bc_gid); S.bc_rep.push_back(pi); }
+                    else {                                   // hash collision: the string decides
+                        auto r = S.bc_str.emplace(std::string(qn.substr(c2 + 1, c1 - c2 - 1)), (int)S.bc_rep.size());
+                        if (r.second) S.bc_rep.push_back(pi);
+                        a.bc_gid = r.first->second;
+                    }
+                }
+                if (((a.h_pair >> 20) & msk) == (uint64_t)t) {
+                    auto it = S.hp.find(a.h_pair);
+                    const bool hit = it != S.hp.end() && [&] {
+                        const Aln& o = parsed[S.pair_rep[(size_t)it->second]];
+                        return o.c2 == a.c2 && bc_equal(o, a) && memcmp(o.qname.data(), qn.data(), c2) == 0;
+                    }();
+                    if (hit) a.pair_gid = it->second;
+                    else if (it == S.hp.end()) { a.pair_gid = (int)S.pair_rep.size(); S.hp.emplace(a.h_pair, a.pair_gid); S.pair_rep.push_back(pi); }
+                    else {
+                        auto r = S.pair_str.emplace(std::string(qn.substr(c2 + 1, c1 - c2 - 1)) + "\x01" + std::string(qn.substr(0, c2)), (int)S.pair_rep.size());
+                        if (r.second) S.pair_rep.push_back(pi);
+                        a.pair_gid = r.first->second;
+                    }
+                }
+            }
+        };
+        if (SH == 1) intern(0);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < SH; ++t) th.emplace_back(intern, t);
+            for (auto& x : th) x.join();
+        }
+        std::vector<int> bc_off((size_t)SH + 1, 0), pair_off((size_t)SH + 1, 0);
+        for (int t = 0; t < SH; ++t) {
+            bc_off[(size_t)t + 1] = bc_off[(size_t)t] + (int)shards[(size_t)t].bc_rep.size();
+            pair_off[(size_t)t + 1] = pair_off[(size_t)t] + (int)shards[(size_t)t].pair_rep.size();
+        }
+        if (bc_names) {
+            bc_names->assign((size_t)bc_off[(size_t)SH], std::string());
+            for (int t = 0; t < SH; ++t)
+                for (size_t k = 0; k < shards[(size_t)t].bc_rep.size(); ++k) {
+                    const Aln& o = parsed[shards[(size_t)t].bc_rep[k]];
+                    (*bc_names)[(size_t)bc_off[(size_t)t] + k] = std::string(o.qname.substr((size_t)o.c2 + 1, (size_t)(o.c1 - o.c2 - 1)));
+                }
+        }
+        reads.reserve(n_keep);
+        {
+            const uint64_t msk = (uint64_t)SH - 1;
+            for (size_t pi = 0; pi < parsed.size(); ++pi) {
+                if (!keep[pi]) continue;
+                Aln& a = parsed[pi];
+                a.bc_gid += bc_off[(size_t)((a.h_bc >> 20) & msk)];
+                a.pair_gid += pair_off[(size_t)((a.h_pair >> 20) & msk)];
+                reads.push_back(std::move(a));
+            }
+        }
+        const std::vector<int>& bc_rep = bc_off; const std::vector<int>& pair_rep = pair_off;    // (sizes below)
+        n_bc = bc_off[(size_t)SH]; n_pair = pair_off[(size_t)SH];
+        (void)bc_rep; (void)pair_rep;
+        if (getenv("SMC_BAM_TIMING")) {
+            const auto tc3 = std::chrono::steady_clock::now();
+            auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            fprintf(stderr, "collect_reads: %zu records, %zu kept: inflate + boundaries %.1f ms, parse %.1f ms, intern %.1f ms (%zu KB inflated)\n",
+                    recs.size(), reads.size(), ms(tc0, tc1), ms(tc1, tc2), ms(tc2, tc3), b.rec_data.size() >> 10);
+        }
         if (!have_first) { b.cur_tid = tid; b.cur_start = start0; b.cur_voff = recs.empty() ? voff : bs.voffset_of(recs.back().first - 4); }
         if (!b.err.empty()) return -2;                  // corrupt / truncated BGZF
     }
-    if (bc_names) { bc_names->assign((size_t)n_bc, std::string()); for (const auto& kv : bc_ids) (*bc_names)[(size_t)kv.second] = kv.first; }
     return 0;
 }
 
@@ -883,26 +970,53 @@ int64_t smc_bam_alignments(void* h, const char* chrom, int64_t start0, int64_t e
     smc_dev_aln* pa = (smc_dev_aln*)bufs[0]; uint32_t* pc = (uint32_t*)bufs[1];
     uint8_t* ps = (uint8_t*)bufs[2]; uint8_t* pq = (uint8_t*)bufs[3]; smc_dev_locus* pl = (smc_dev_locus*)bufs[4];
     if ((!reads.empty() && (!pa || !pc || !ps || !pq)) || (nl && !pl)) { b.err = "smc_bam_alignments: allocation callback returned no memory"; return -9; }
-    size_t oc = 0, os = 0;
-    int st = 0;
-    for (size_t i = 0; i < reads.size(); ++i) {
-        const Aln& a = reads[i];
-        smc_dev_aln& d = pa[i];
-        d.pos = a.pos; d.end = a.end;
-        d.cig_off = (uint32_t)oc; d.seq_off = (uint32_t)os;
-        if (a.cigar.n > 65535 || a.left_sp > 65535 || a.qalen > 65535 || a.l_seq > 65535) st |= 2;
-        d.n_cig = (uint16_t)a.cigar.n;
-        const int64_t mism = std::max<int64_t>(0, (int64_t)a.nm - (int64_t)a.n_ind);
-        const double mm100 = a.l_seq > 0 ? 100.0 * (double)mism / (double)a.l_seq : 0.0;     // smCounter.py:352-356
-        if (!(a.oflag & 3)) st |= 1;
-        d.oflag = (uint8_t)((a.oflag & 7) | (mm100 <= mismatch_thr ? SMC_DA_MMOK : 0));
-        d.mapq = a.mapq;
-        d.left_sp = (uint16_t)a.left_sp; d.qalen = (uint16_t)a.qalen;
-        d.l_seq = (uint16_t)a.l_seq; d.pad = 0;
-        d.bc_gid = (uint32_t)a.bc_gid; d.pair_gid = (uint32_t)a.pair_gid;
-        for (uint32_t c : a.cigar) pc[oc++] = c;
-        for (uint32_t k = 0; k < a.l_seq; ++k) { ps[os] = (uint8_t)a.seq[k]; pq[os] = a.qual[k]; ++os; }
+    // offsets of every alignment's CIGAR words and bases in the pools, then the records and pools are filled by the threads
+    std::vector<uint32_t> offc(reads.size() + 1, 0), offs(reads.size() + 1, 0);
+    for (size_t i = 0; i < reads.size(); ++i) { offc[i + 1] = offc[i] + reads[i].cigar.n; offs[i + 1] = offs[i] + reads[i].l_seq; }
+    std::atomic<int> st_bits(0);
+    const auto t_p0 = std::chrono::steady_clock::now();
+    {
+        static const char* const CODE = "=ACMGRSVTWYHKDBN";
+        const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)nthreads, reads.size() / 4096 + 1));
+        auto work = [&](int t) {
+            const size_t lo = reads.size() * (size_t)t / (size_t)T, hi = reads.size() * (size_t)(t + 1) / (size_t)T;
+            int st = 0;
+            for (size_t i = lo; i < hi; ++i) {
+                const Aln& a = reads[i];
+                smc_dev_aln& d = pa[i];
+                d.pos = a.pos; d.end = a.end;
+                d.cig_off = offc[i]; d.seq_off = offs[i];
+                if (a.cigar.n > 65535 || a.left_sp > 65535 || a.qalen > 65535 || a.l_seq > 65535) st |= 2;
+                d.n_cig = (uint16_t)a.cigar.n;
+                const int64_t mism = std::max<int64_t>(0, (int64_t)a.nm - (int64_t)a.n_ind);
+                const double mm100 = a.l_seq > 0 ? 100.0 * (double)mism / (double)a.l_seq : 0.0;     // smCounter.py:352-356
+                if (!(a.oflag & 3)) st |= 1;
+                d.oflag = (uint8_t)((a.oflag & 7) | (mm100 <= mismatch_thr ? SMC_DA_MMOK : 0));
+                d.mapq = a.mapq;
+                d.left_sp = (uint16_t)a.left_sp; d.qalen = (uint16_t)a.qalen;
+                d.l_seq = (uint16_t)a.l_seq; d.pad = 0;
+                d.bc_gid = (uint32_t)a.bc_gid; d.pair_gid = (uint32_t)a.pair_gid;
+                uint32_t* c = pc + offc[i];
+                for (uint32_t w : a.cigar) *c++ = w;
+                uint8_t* sq = ps + offs[i];
+                const uint8_t* packed = a.seq.p;
+                for (uint32_t k = 0; k + 1 < a.l_seq; k += 2) { const uint8_t b2 = packed[k >> 1]; sq[k] = (uint8_t)CODE[b2 >> 4]; sq[k + 1] = (uint8_t)CODE[b2 & 15]; }
+                if (a.l_seq & 1) sq[a.l_seq - 1] = (uint8_t)CODE[packed[(a.l_seq - 1) >> 1] >> 4];
+                memcpy(pq + offs[i], a.qual.p, a.l_seq);
+            }
+            if (st) st_bits.fetch_or(st);
+        };
+        if (T == 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; ++t) th.emplace_back(work, t);
+            for (auto& x : th) x.join();
+        }
     }
+    const int st = st_bits.load();
+    if (getenv("SMC_BAM_TIMING"))
+        fprintf(stderr, "smc_bam_alignments: %zu alignments, %lld loci, %lld reads: pack %.1f ms\n", reads.size(), (long long)nl,
+                (long long)total, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_p0).count());
     // candidate window of every locus: [first alignment that ends behind it ... first alignment that starts behind it)
     size_t w0 = 0, w1 = 0;
     for (int64_t l = 0; l < nl; ++l) {

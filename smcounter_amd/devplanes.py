@@ -21,10 +21,14 @@ from .features import LF_SAMPLED, LOCUS_DTYPE, USTART_DROPPED
 from .pileup import BASE_ALLELES
 
 
+_TIMES = {"decode": 0.0, "upload+launch": 0.0, "kernel (sync)": 0.0}      # SMC_DEVPLANES_TIMING=1: seconds per stage
+
+
 @dataclasses.dataclass
 class ResidentBatch:
-    """A batch whose planes live in HBM (torch tensors); the descriptors and what row formatting needs are on the host."""
-    planes: list               # [meta, umi, frag, dist, umi_start] int32 CUDA tensors
+    """A batch whose planes live in HBM (engine.DevBuf allocations: no PyTorch in this path); the descriptors and what row
+    formatting needs are on the host."""
+    planes: list               # [meta, umi, frag, dist, umi_start] device buffers (`data_ptr()`), uint32 words
     loci: np.ndarray           # LOCUS_DTYPE[n_loci] (host copy; offsets are batch-relative)
     chrom: List[str]
     pos: np.ndarray
@@ -32,6 +36,8 @@ class ResidentBatch:
     alleles: List[List[str]]
     n_device_runs: int = 0     # runs built by k_build_planes / by the host builder (fallback)
     n_host_runs: int = 0
+    n_slots: int = 0
+    n_ustart: int = 0
 
     @property
     def n_loci(self) -> int:
@@ -40,35 +46,40 @@ class ResidentBatch:
     def to_host(self):
         """-> features.DeviceBatch with the planes copied back (tests, the CPU restatement)."""
         from .features import DeviceBatch
-        m, u, f, d, us = (t.cpu().numpy().view(np.uint32) for t in self.planes)
+        m, u, f, d = (t.download(np.uint32, self.n_slots) for t in self.planes[:4])
+        us = self.planes[4].download(np.uint32, self.n_ustart)
         return DeviceBatch(loci=self.loci.copy(), meta=m, umi=u, frag=f, dist=d, umi_start=us, chrom=list(self.chrom),
                            pos=self.pos.copy(), ref=list(self.ref), alleles=[list(t) for t in self.alleles])
 
 
-def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], params, eng, max_reads: int = 4_000_000,
+def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], params, eng, max_reads: int = 32_000_000,
                           nthreads: int = 0, force_host: bool = False):
     """BAM -> `ResidentBatch` chunks: same loci per chunk as bamio.iter_device_batches_native, planes built on the GPU."""
-    import torch
+    from .engine import DevBuf
     L = eng.L
-    dev = torch.device("cuda", eng.device)
     bam = bamio.NativeBam(path)
     nthreads = nthreads or len(os.sched_getaffinity(0))
     max_depth = L.smc_build_max_depth()
     cp = abi.c_params(params)
-    st = torch.cuda.current_stream(eng.device)
     i, n = 0, len(loci)
     cap = max_reads + (max_reads >> 3) + 65536
+    per_locus = 0.0          # pileup reads per locus of the previous run: sizes the next run (a run is decoded as a whole)
     while i < n:
         first = i
-        planes = [torch.empty(cap, dtype=torch.int32, device=dev) for _ in range(4)]
-        uaux = [torch.empty(cap + 8192, dtype=torch.int32, device=dev) for _ in range(3)]      # umi_start, u_gid, u_finc
+        planes = [DevBuf(eng, 4 * cap) for _ in range(4)]
+        uaux = [DevBuf(eng, 4 * (cap + 8192)) for _ in range(3)]      # umi_start, u_gid, u_finc
         LC, chroms, poss, refs, tables = [], [], [], [], []
         total = slots = n_loc = 0
         n_dev = n_host = 0
         while i < n and total < max_reads:
             chrom = loci[i][0]
             j = i
-            while j + 1 < n and loci[j + 1][0] == chrom and int(loci[j + 1][1]) == int(loci[j][1]) + 1 and j + 1 - i < 4096:
+            # (the decoder inflates everything up to the run's end: a run much longer than what max_reads lets through
+            # would be decoded again by the next one)
+            span_cap = 65536 if per_locus <= 0 else int(max(1024, min(65536, 1.15 * (max_reads - total) / per_locus)))
+            if per_locus <= 0 and i == first:
+                span_cap = 8192
+            while j + 1 < n and loci[j + 1][0] == chrom and int(loci[j + 1][1]) == int(loci[j][1]) + 1 and j + 1 - i < span_cap:
                 j += 1
             lo, hi = int(loci[i][1]) - 1, int(loci[j][1])
             run_ref = fasta.fetch(chrom, lo, hi).upper()
@@ -76,7 +87,7 @@ def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], par
             done = None
             if not force_host:
                 done = _device_run(bam, L, eng, cp, params, chrom, lo, hi, max_reads - total, nthreads, fasta, run_ref, planes, uaux,
-                                   slots, umi_base, cap, max_depth, dev, st)
+                                   slots, umi_base, cap, max_depth)
             if done is None:
                 # host builder (the run is not one the device path takes): same planes, uploaded
                 nl, hp, ustart, lc, tb = bam.planes_run(chrom, lo, hi, max_reads - total, params, run_ref, nthreads, fasta)
@@ -84,8 +95,8 @@ def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], par
                 if slots + ns > cap or umi_base + len(ustart) > cap + 8192:
                     raise bamio.BamError("run of %d read slots does not fit the device arena" % ns)
                 for k in range(4):
-                    planes[k][slots:slots + ns].copy_(torch.from_numpy(hp[k].view(np.int32)))
-                uaux[0][umi_base:umi_base + len(ustart)].copy_(torch.from_numpy(ustart.view(np.int32)))
+                    planes[k].upload(hp[k], 4 * slots)
+                uaux[0].upload(ustart, 4 * umi_base)
                 lc = lc.copy()
                 lc["read_off4"] += slots // 4
                 lc["umi_off"] += umi_base
@@ -94,6 +105,8 @@ def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], par
                 nl, ns, lc, tb = done
                 n_dev += 1
             LC.append(lc)
+            if nl:
+                per_locus = max(1.0, float(lc["n_reads"].sum()) / nl)
             slots += ns
             n_loc += nl
             total += int(lc["n_reads"].sum())
@@ -103,52 +116,58 @@ def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], par
             tables += tb
             i += nl
         lc_all = LC[0] if len(LC) == 1 else np.concatenate(LC)
-        yield first, ResidentBatch(planes=[planes[0][:slots], planes[1][:slots], planes[2][:slots], planes[3][:slots],
-                                           uaux[0][:slots + n_loc + 1]],
+        uaux[1].free(); uaux[2].free()
+        yield first, ResidentBatch(planes=planes + [uaux[0]], n_slots=slots, n_ustart=slots + n_loc + 1,
                                    loci=lc_all, chrom=chroms, pos=np.array(poss, np.int64), ref=refs, alleles=tables,
                                    n_device_runs=n_dev, n_host_runs=n_host)
     bam.close()
 
 
 def _device_run(bam, L, eng, cp, params, chrom, lo, hi, max_reads, nthreads, fasta, run_ref, planes, uaux, slot_base, umi_base,
-                cap, max_depth, dev, st):
+                cap, max_depth):
     """One run through smc_bam_alignments + smc_build_planes.  -> (n loci, slots, descriptors, allele tables) or None
     when the run has to take the host builder."""
-    import torch
+    import time
+    from .engine import DevBuf
+    T = _TIMES if os.environ.get("SMC_DEVPLANES_TIMING") else None
+    t0 = time.perf_counter()
     A = bam.alignments_run(chrom, lo, hi, max_reads, params, nthreads)
+    t1 = time.perf_counter()
     nl, ns = A["nl"], A["n_slots"]
     if nl == 0:
         return 0, 0, np.zeros(0, LOCUS_DTYPE), []
     if A["status"] != 0 or (len(A["loc"]) and int(A["loc"]["n"].max()) > max_depth) or slot_base + ns > cap or \
             umi_base + ns + nl + 1 > cap + 8192:
         return None
-    up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev, non_blocking=False)
-    d_aln = up(A["aln"].view(np.uint8) if len(A["aln"]) else np.zeros(36, np.uint8), np.uint8)
-    d_cig, d_seq, d_qual = up(A["cig"], np.int32), up(A["seq"], np.uint8), up(A["qual"], np.uint8)
-    d_loc = up(A["loc"].view(np.uint8), np.uint8)
-    d_ref = up(np.frombuffer(run_ref[:nl].encode().ljust(nl, b"\0"), np.uint8).copy(), np.uint8)
-    d_loci = torch.empty(nl * LOCUS_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    up = lambda a: DevBuf(eng, max(4, a.nbytes)).upload(a.view(np.uint8).reshape(-1) if a.nbytes else np.zeros(4, np.uint8))
+    d_aln, d_cig, d_seq, d_qual, d_loc = up(A["aln"]), up(A["cig"]), up(A["seq"]), up(A["qual"]), up(A["loc"])
+    d_ref = up(np.frombuffer(run_ref[:nl].encode().ljust(nl, b"\0"), np.uint8).copy())
+    d_loci = DevBuf(eng, nl * LOCUS_DTYPE.itemsize)
     xcap = 4 * nl + 4096
-    d_x = torch.empty(5 * xcap, dtype=torch.int32, device=dev)
-    d_cnt = torch.zeros(2, dtype=torch.int32, device=dev)
+    d_x = DevBuf(eng, 20 * xcap)
+    d_cnt = DevBuf(eng, 8)
     bi = abi.SmcBuildIn(d_aln.data_ptr(), d_cig.data_ptr(), d_seq.data_ptr(), d_qual.data_ptr(), d_loc.data_ptr(), d_ref.data_ptr(),
                         lo, nl, A["n_bc"], A["n_pair"])
     _lib.check(L.smc_build_planes(eng.ctx, ctypes.byref(cp), ctypes.byref(bi), slot_base, umi_base, planes[0].data_ptr(),
                                   planes[1].data_ptr(), planes[2].data_ptr(), planes[3].data_ptr(), uaux[0].data_ptr(),
                                   uaux[1].data_ptr(), uaux[2].data_ptr(), d_loci.data_ptr(), d_x.data_ptr(), xcap,
-                                  d_cnt.data_ptr(), ctypes.c_void_p(st.cuda_stream)), "smc_build_planes")
-    cnt = d_cnt.cpu().numpy().view(np.uint32)
+                                  d_cnt.data_ptr(), ctypes.c_void_p(0)), "smc_build_planes")
+    t2 = time.perf_counter()
+    cnt = d_cnt.download(np.uint32, 2)        # (a copy on the default stream: behind the kernel)
+    t3 = time.perf_counter()
+    if T is not None:
+        T["decode"] += t1 - t0; T["upload+launch"] += t2 - t1; T["kernel (sync)"] += t3 - t2
     if int(cnt[1]) != 0 or int(cnt[0]) > xcap:
         if int(cnt[1]) & 4:
             from .features import PileupError
             raise PileupError("base quality > 126 at %s:%d-%d" % (chrom, lo + 1, lo + nl))
         return None
-    lc = d_loci.cpu().numpy().view(LOCUS_DTYPE).copy()
+    lc = d_loci.download(LOCUS_DTYPE, nl)
     # allele tables: the six fixed keys + what the kernel met, in the order it numbered them
     tables = [list(BASE_ALLELES) for _ in range(nl)]
     nx = int(cnt[0])
     if nx:
-        xl = d_x[:5 * nx].cpu().numpy().view(np.uint32).reshape(nx, 5)
+        xl = d_x.download(np.uint32, 5 * nx).reshape(nx, 5)
         xl = xl[np.lexsort((xl[:, 1], xl[:, 0]))]
         for l, aid, ai, qpos, indel in xl.tolist():
             key = bam.allele_key(ai, qpos, np.int32(np.uint32(indel)))
@@ -164,9 +183,9 @@ def _device_run(bam, L, eng, cp, params, chrom, lo, hi, max_reads, nthreads, fas
         from .py2compat import py2_downsample_barcodes
         for l in over.tolist():
             o, nu = int(lc["umi_off"][l]), int(lc["n_umi"][l])
-            us = uaux[0][o:o + nu].cpu().numpy().view(np.uint32).copy()
-            gid = uaux[1][o:o + nu].cpu().numpy().view(np.uint32)
-            finc = uaux[2][o:o + nu].cpu().numpy().view(np.uint32)
+            us = uaux[0].download(np.uint32, nu, 4 * o)
+            gid = uaux[1].download(np.uint32, nu, 4 * o)
+            finc = uaux[2].download(np.uint32, nu, 4 * o)
             keys = np.nonzero(finc != 0xFFFFFFFF)[0]
             keys = keys[np.argsort(finc[keys], kind="stable")]
             if len(keys) <= params.ds:
@@ -176,6 +195,6 @@ def _device_run(bam, L, eng, cp, params, chrom, lo, hi, max_reads, nthreads, fas
             for u, name in zip(keys.tolist(), names):
                 if name not in kept:
                     us[u] |= USTART_DROPPED
-            uaux[0][o:o + nu].copy_(torch.from_numpy(us.view(np.int32)))
+            uaux[0].upload(us, 4 * o)
             lc["flags"][l] |= LF_SAMPLED
     return nl, ns, lc, tables

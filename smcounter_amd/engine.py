@@ -15,6 +15,55 @@ from .features import DeviceBatch
 from .params import VcParams
 
 
+class DevBuf(object):
+    """A device allocation owned through the C ABI (smc_mem_*): what the command line uses instead of a torch tensor, so
+    that a single-process run never imports PyTorch.  Quacks like one where the bindings need it (`data_ptr()`)."""
+
+    def __init__(self, eng, nbytes: int):
+        self.eng, self.nbytes = eng, int(nbytes)
+        p = ctypes.c_void_p()
+        _lib.check(eng.L.smc_mem_alloc(eng.ctx, self.nbytes, ctypes.byref(p)), "smc_mem_alloc")
+        self.ptr = p.value or 0
+
+    def data_ptr(self) -> int:
+        return self.ptr
+
+    def upload(self, arr: np.ndarray, offset_bytes: int = 0):
+        arr = np.ascontiguousarray(arr)
+        assert offset_bytes + arr.nbytes <= self.nbytes
+        _lib.check(self.eng.L.smc_mem_h2d(self.eng.ctx, self.ptr + offset_bytes, arr.ctypes.data, arr.nbytes), "smc_mem_h2d")
+        return self
+
+    def download(self, dtype, count: int, offset_bytes: int = 0) -> np.ndarray:
+        out = np.empty(count, dtype)
+        assert offset_bytes + out.nbytes <= self.nbytes
+        _lib.check(self.eng.L.smc_mem_d2h(self.eng.ctx, out.ctypes.data, self.ptr + offset_bytes, out.nbytes), "smc_mem_d2h")
+        return out
+
+    def view(self, offset_bytes: int):
+        """A pointer into the allocation (no ownership)."""
+        return _DevView(self.ptr + offset_bytes)
+
+    def free(self):
+        if self.ptr and self.eng.ctx:
+            self.eng.L.smc_mem_free(self.eng.ctx, self.ptr)
+        self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class _DevView(object):
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def data_ptr(self) -> int:
+        return self.ptr
+
+
 class Engine(object):
     def __init__(self, device: int = 0):
         self.L = _lib.load()
@@ -73,16 +122,29 @@ class Plan(object):
                            device=torch.device("cuda", self.eng.device))
 
     def run(self, planes, params: VcParams, rows=None, stream=None):
-        """Enqueue the hot path on `stream` (a torch.cuda.Stream; default: torch's current one)."""
-        import torch
+        """Enqueue the hot path on `stream` (a torch.cuda.Stream; default: torch's current one; 0: the default HIP stream,
+        without touching torch - the DevBuf path)."""
+        if stream == 0:
+            st_ptr = ctypes.c_void_p(0)
+        else:
+            import torch
+            st = stream if stream is not None else torch.cuda.current_stream(self.eng.device)
+            st_ptr = ctypes.c_void_p(st.cuda_stream)
         if rows is None:
             rows = self.alloc_rows()
-        st = stream if stream is not None else torch.cuda.current_stream(self.eng.device)
         cp = abi.c_params(params)
         _lib.check(self.eng.L.smc_plan_run(self.h, ctypes.byref(cp), planes[0].data_ptr(), planes[1].data_ptr(),
                                            planes[2].data_ptr(), planes[3].data_ptr(), planes[4].data_ptr(),
-                                           rows.data_ptr(), ctypes.c_void_p(st.cuda_stream)), "smc_plan_run")
+                                           rows.data_ptr(), st_ptr), "smc_plan_run")
         return rows
+
+    def run_devbuf(self, planes, params: VcParams) -> np.ndarray:
+        """The torch-free path: planes are DevBuf / views, the rows come back as a numpy array (synchronous)."""
+        rows = DevBuf(self.eng, self.n_loci * abi.ROW_DTYPE.itemsize)
+        self.run(planes, params, rows, stream=0)
+        out = rows.download(abi.ROW_DTYPE, self.n_loci)     # (hipMemcpy on the default stream: ordered behind the kernels)
+        rows.free()
+        return out
 
     def alloc_wire(self):
         """Device buffer for the packed wire rows of this plan's loci (abi.WIRE_DTYPE, 168 B per locus)."""

@@ -46,7 +46,7 @@ def vc_resident(rb, params: VcParams, refprov, eng: _engine.Engine) -> List[str]
     plan, kernels, rows back, strings - no plane ever crosses PCIe."""
     plan = eng.make_plan(rb.loci)
     try:
-        out_rows = plan.download(plan.run(rb.planes, params))
+        out_rows = plan.run_devbuf(rb.planes, params)
     finally:
         plan.close()
     text = []

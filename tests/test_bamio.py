@@ -242,9 +242,12 @@ def _assert_device_batches_equal(a, b):
 
 
 @pytest.mark.parametrize("mt_depth", [1000, 4])        # 4 -> ds = 8 < 25 barcodes: the py2 down-sampling path
-@pytest.mark.parametrize("nthreads", [1, 3])
+@pytest.mark.parametrize("nthreads", [1, 3, "4 shards"])   # ("4 shards": barcode / read-name interning sharded by hash over threads)
 @pytest.mark.parametrize("max_reads", [5000, 2_000_000])
-def test_native_fused_planes_match_extract_features(tmp_path, max_reads, nthreads, mt_depth):
+def test_native_fused_planes_match_extract_features(tmp_path, max_reads, nthreads, mt_depth, monkeypatch):
+    if nthreads == "4 shards":
+        monkeypatch.setenv("SMC_BAM_SHARDS", "4")
+        nthreads = 4
     """smc_bam_planes (decode + features + barcode-major order in one native pass) builds the same
     DeviceBatch, chunk for chunk, as extract_features over the Python decoder's batches."""
     bam, fa_path, loci = _random_bam(tmp_path, 23, True)
