@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 cd /tmp; export TMPDIR=/tmp
 F="-O3 --offload-arch=gfx950 -fPIC -shared -std=c++17 -ffp-contract=off -mllvm -disable-machine-licm -I$R/include"
 cp $R/smcounter_amd/libsmcounter_hip.so /tmp/lib_keep.so
-for ab in 1 2 3 4 0; do
+for ab in ${ABLATES:-1 2 3 4 0}; do
   hipcc $F -DSMC_ABLATE=$ab -o $R/smcounter_amd/libsmcounter_hip.so $R/smcounter_amd/csrc/smcounter_hip.hip
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d $R/$out/a$ab -- python3 $R/scripts/quick_perf.py --cfg C3 --loci 40000 --iters 1 > /dev/null 2>&1
   python3 - $R/$out/a$ab $ab <<'PY'
