@@ -4,7 +4,7 @@
 Metric (BASELINE.json): loci/s at fixed read-depth x reads-per-UMI.  Workload at every N:
 BASELINE.json configs[2] "synthetic 200k loci, 3000x depth, 50 UMIs/locus, 60 rpb" PER GPU (weak
 scaling: rank r calls loci [r*200k, (r+1)*200k) of the same seeded config), inputs resident in HBM
-before the timed region.  A step = one pass of the hot path (k_call_loci bins + k_filter_loci) over
+before the timed region.  A step = one pass of the hot path (k_call_v2 bins + k_filter_loci) over
 the rank's batch, followed, for N > 1, by the gather of the rows to rank 0 (RCCL; the gather of a step
 overlaps the next step's kernels, two row buffers per rank - every step's rows are gathered inside the
 timed region).
@@ -120,7 +120,7 @@ def roofline_block(plan_loci, k_ms, k_n, k_loci, k_reads, cfg_key):
             traffic_bytes = rec["hbm_bytes_per_launch"]
             traffic = traffic_bytes / (k_ms * 1e-3) / 1e9
             src = "profiles/traffic.json <- " + rec.get("source", "rocprofv3 --pmc")
-    return {"bound": "hbm", "kernel": "k_call_loci", "achieved": achieved, "peak": HBM_PEAK_GBS,
+    return {"bound": "hbm", "kernel": "k_call_v2", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
             "kernel_ms": k_ms, "kernel_samples": k_n, "loci_per_launch": k_loci,
             "alg_bytes_per_launch": alg_bytes, "needed_bytes_per_launch": need,
@@ -259,7 +259,7 @@ def main():
                        "value_from": "median block", "spread_pct": round(100.0 * (max(blocks) - min(blocks)) / elapsed, 2)},
             "roofline": roofline_block(res.loci, k_ms, k_n, k_loci, k_reads, "%s:%d" % (a.config, n_loc)),
             "host_buffers": "inputs resident in HBM when the timed region starts; handing host buffers instead "
-                            "(smc_call_batch_host: H2D of 8 B/read + kernels + D2H of the rows) measured 1.81 M loci/s on C3 "
+                            "(smc_call_batch_host: H2D of 8 B/read + kernels + D2H of the rows) measured 1.92 M loci/s on C3 "
                             "(DESIGN.md section 5) - PCIe-bound, never `value`",
         }
         if cpu is not None:

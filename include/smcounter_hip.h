@@ -281,7 +281,7 @@ void smc_plan_destroy(smc_plan* plan);
 /* number of kernel launches one smc_plan_run issues, and bytes of device scratch it holds */
 int smc_plan_info(const smc_plan* plan, int32_t* n_launches, int64_t* scratch_bytes);
 
-/* Optional: bracket the dominant k_call_loci launch (the bin holding most reads) of each
+/* Optional: bracket the dominant k_call_v2 launch (the bin holding most reads) of each
  * smc_plan_run with a HIP event pair on the run's stream, kept in a ring of `slots` pairs
  * (0 disables). smc_plan_kernel_ms synchronises on the recorded pairs and returns that launch's
  * mean duration over the last min(runs, slots) runs, with the loci and reads one launch covers. */
@@ -289,7 +289,7 @@ int smc_plan_set_timing(smc_plan* plan, int slots);
 int smc_plan_kernel_ms(smc_plan* plan, float* avg_ms, int32_t* n_samples, int64_t* n_loci, int64_t* n_reads);
 
 /* Run the hot path over the batch. meta/umi/frag/dist, umi_start and rows are DEVICE pointers
- * (planes n_slots x uint32 each; umi_start sum(n_umi + 1) x uint32; rows n_loci x smc_row). `stream` is a hipStream_t (NULL = default
+ * (planes n_slots x uint32 each, umi and dist may be NULL - the kernels do not read them; umi_start sum(n_umi + 1) x uint32; rows n_loci x smc_row). `stream` is a hipStream_t (NULL = default
  * stream). Asynchronous: returns after enqueueing. */
 int smc_plan_run(smc_plan* plan, const smc_params* params, const uint32_t* meta,
                  const uint32_t* umi, const uint32_t* frag, const uint32_t* dist,

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Dev tool: VALU / SALU wave-instruction counts of k_call_loci per phase, from ablation builds (SMC_ABLATE=n returns
+# Dev tool: VALU / SALU wave-instruction counts of k_call_v2 per phase, from ablation builds (SMC_ABLATE=n returns
 # after phase n) under rocprofv3 --pmc.  usage: bash scripts/phase_valu.sh gpurun_out/phase_valu
 out=$1
 R=$GRAFT_REPO_ROOT

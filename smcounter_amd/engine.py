@@ -171,7 +171,7 @@ class Plan(object):
         _lib.check(self.eng.L.smc_plan_set_timing(self.h, int(slots)), "smc_plan_set_timing")
 
     def kernel_ms(self):
-        """(mean ms, samples, loci, reads) of the dominant k_call_loci launch over the timed runs."""
+        """(mean ms, samples, loci, reads) of the dominant k_call_v2 launch over the timed runs."""
         ms, ns, nl, nr = ctypes.c_float(), ctypes.c_int32(), ctypes.c_int64(), ctypes.c_int64()
         _lib.check(self.eng.L.smc_plan_kernel_ms(self.h, ctypes.byref(ms), ctypes.byref(ns), ctypes.byref(nl),
                                                  ctypes.byref(nr)), "smc_plan_kernel_ms")
