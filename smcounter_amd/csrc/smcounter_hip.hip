@@ -24,6 +24,7 @@
 // This is integer/branchy, HBM-streaming work: no MFMA.
 #include <hip/hip_runtime.h>
 
+#include <limits.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -31,7 +32,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "smcounter_hip.h"

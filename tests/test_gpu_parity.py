@@ -164,6 +164,39 @@ def test_parts_and_chunks_give_identical_rows(monkeypatch):
     eng.close()
 
 
+def test_general_path_with_and_without_the_reference_fragment_shortcut(monkeypatch):
+    """A queued barcode with P.lite_from or more reference-allele fragments is scored from the odds of its OTHER fragments
+    only (calProb's likelihoods all carry rightP, smCounter.py:62-91; host_abi.inc lite_from_for): the rows must equal the
+    full walk's (SMC_NO_LITE=1) in every integer column, PI far inside the tolerance; below the bound (C2's ~7 fragments
+    per barcode; minBQ = 0, where the bound does not exist) nothing may change at all."""
+    import dataclasses
+    from smcounter_amd import engine
+    eng = engine.Engine(0)
+    for name, n, same_bytes in (("C3", 600, False), ("X3", 400, False), ("C5", 200, False), ("C2", 2000, True)):
+        cfg = synth.CONFIGS[name]
+        P = synth.params_for(cfg)
+        db = synth.generate_native(cfg, 0, n, P)
+        lite = eng.call_batch_host(db, P)
+        monkeypatch.setenv("SMC_NO_LITE", "1")
+        full = eng.call_batch_host(db, P)
+        monkeypatch.delenv("SMC_NO_LITE")
+        if same_bytes:
+            assert lite.tobytes() == full.tobytes(), name
+            continue
+        assert lite.tobytes() != full.tobytes(), name           # (the shortcut was taken)
+        assert abi.compare_rows(lite, full, 1e-9, 1e-12) == [], name
+        want, fragile = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE, return_fragile=True)
+        assert abi.compare_rows(lite, want, PI_TOL, P_TOL, fragile) == [], name
+    cfg = synth.CONFIGS["C3"]
+    P0 = dataclasses.replace(synth.params_for(cfg), minBQ=0)
+    db = synth.generate_native(cfg, 0, 300, P0)
+    lite = eng.call_batch_host(db, P0)
+    monkeypatch.setenv("SMC_NO_LITE", "1")
+    assert eng.call_batch_host(db, P0).tobytes() == lite.tobytes()
+    monkeypatch.delenv("SMC_NO_LITE")
+    eng.close()
+
+
 def test_locus_above_2_to_18_reads(engine0):
     """312,000 reads on one locus (the kernel takes up to 2^24; pysam's max_depth in the reference is 10^6): 22 parts,
     rows equal to the CPU restatement."""
