@@ -336,6 +336,9 @@ int smc_build_planes(smc_ctx* ctx, const smc_params* params, const smc_build_in*
  * PyTorch: about a second of start-up): allocation, synchronous copies, device synchronisation. */
 int smc_mem_alloc(smc_ctx* ctx, int64_t bytes, void** out);
 void smc_mem_free(smc_ctx* ctx, void* p);
+/* page-locked host memory: copies to and from it run at the link's rate (pageable memory goes through a staging copy) */
+int smc_mem_alloc_host(smc_ctx* ctx, int64_t bytes, void** out);
+void smc_mem_free_host(smc_ctx* ctx, void* p);
 int smc_mem_h2d(smc_ctx* ctx, void* dst_device, const void* src_host, int64_t bytes);
 int smc_mem_d2h(smc_ctx* ctx, void* dst_host, const void* src_device, int64_t bytes);
 int smc_device_sync(smc_ctx* ctx);

@@ -76,6 +76,17 @@ int smc_rowfmt_stride(void);
  * chosen[i] < 0, status != 0, a zero denominator or |value| >= 1e8 leave an EMPTY line: the caller prints that row
  * itself.  `out` holds n * smc_rowfmt_stride() bytes; returns the bytes written. */
 int64_t smc_format_tails(const smc_row* rows, const int8_t* chosen, int64_t n, char* out);
+/* The same with the whole line where that needs no string work: for a row with alt[i] != 0 (and ref[i] != 0) the line is
+ * CHROM, POS, ref[i], alt[i], "SNP", the 39 columns and the raw FILTER ";" of a locus no filter applies to - what vc()
+ * returns for it (smCounter.py:599); for the other rows just the 39 columns, as smc_format_tails (the caller adds
+ * CHROM..TYPE and FILTER).  Chromosome names: chroms[chrom_off[c] .. chrom_off[c + 1]) for c = chrom_id[i].  pred[i]
+ * (optional) = int(float(<the PI column as printed>)) - what the repeat filters and the writers compare (:757, :838) -
+ * or INT32_MIN for a row left empty.  `out` holds n * smc_rowfmt_line_stride(longest chromosome name) bytes; up to
+ * `nthreads` (<= 16) threads print stretches of rows.  Returns the bytes written. */
+int smc_rowfmt_line_stride(int max_chrom_len);
+int64_t smc_format_lines(const smc_row* rows, const int8_t* chosen, int64_t n, const char* chroms, const int32_t* chrom_off,
+                         const int32_t* chrom_id, const int64_t* pos, const uint8_t* ref, const uint8_t* alt, int max_chrom_len,
+                         int nthreads, char* out, int32_t* pred);
 
 #ifdef __cplusplus
 }

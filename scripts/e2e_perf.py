@@ -53,6 +53,8 @@ P = VcParams(mtDepth=max(1, depth // rpu), rpb=float(rpu), hpLen=8)
 ref_f = fasta.FastaFile(fa)
 loci = bedops.expand_loci(bed)
 from smcounter_amd.engine import Engine
+import gc
+gc.disable()          # as cli.main does for the duration of a run
 import torch
 eng = Engine(0)
 for rep in range(2):
@@ -83,7 +85,7 @@ for rep in range(2):
               len(out) / (t6 - t)))
 
 # planes built on the device (the default of the command line): host decodes alignments, k_build_planes builds the planes
-from smcounter_amd import devplanes, vc
+from smcounter_amd import cli, devplanes, vc
 os.environ["SMC_DEVPLANES_TIMING"] = "1"
 os.environ["SMC_BAM_TIMING"] = "1"
 for rep in range(3):
@@ -91,7 +93,7 @@ for rep in range(3):
     torch.cuda.synchronize()
     t = time.time()
     t_bld = t_run = 0.0
-    out2, n_dev, n_host = [], 0, 0
+    out2, n_dev, n_host = cli._Rows(), 0, 0
     it = devplanes.iter_resident_batches(bam, ref_f, loci, P, eng)
     while True:
         t1 = time.time()
@@ -101,16 +103,19 @@ for rep in range(3):
             break
         torch.cuda.synchronize()
         t2 = time.time()
-        out2.extend(vc.vc_resident(rb, P, ref_f, eng))
+        out2.add(vc.vc_resident(rb, P, ref_f, eng))
         t3 = time.time()
         t_bld += t2 - t1; t_run += t3 - t2; n_dev += rb.n_device_runs; n_host += rb.n_host_runs
     t5 = time.time()
-    final2 = postfilter.apply_repeat_filters(out2, {}, {})
-    writers.write_outputs(os.path.join(tmp, "o2"), final2, writers.pi_threshold(P.mtDepth, 0))
+    out2.done()
+    final2 = postfilter.apply_repeat_filters(out2, {}, {}, pred=out2.pred)
+    writers.write_outputs(os.path.join(tmp, "o2"), final2, writers.pi_threshold(P.mtDepth, 0), pred=out2.pred)
     t6 = time.time()
     print("device planes, pass %d: %d loci (%d device runs, %d host runs): decode + upload + k_build_planes %.3fs | kernels + D2H + "
           "row strings %.3fs | post-filter+writers %.3fs | total %.3fs -> %.0f loci/s; rows equal to the host-planes pass: %s" % (
-              rep, len(out2), n_dev, n_host, t_bld, t_run, t6 - t5, t6 - t, len(out2) / (t6 - t), out2 == out))
+              rep, len(out2), n_dev, n_host, t_bld, t_run, t6 - t5, t6 - t, len(out2) / (t6 - t),
+              list(out2) == out and all(open(os.path.join(tmp, "o" + e)).read() == open(os.path.join(tmp, "o2" + e)).read()
+                                        for e in (".smCounter.all.txt", ".smCounter.cut.txt"))))
     print("   stages:", {k: round(v, 4) for k, v in devplanes._TIMES.items()})
 
 os.environ.pop("SMC_BAM_TIMING", None)

@@ -15,6 +15,7 @@ SYMBOLS = ("smc_abi_version", "smc_last_error", "smc_row_size", "smc_locus_size"
            "smc_plan_run", "smc_plan_set_timing", "smc_plan_kernel_ms", "smc_call_batch_host", "smc_event_create", "smc_event_record",
            "smc_event_elapsed_ms", "smc_event_destroy", "smc_class_table", "smc_wire_row_size", "smc_pack_rows", "smc_unpack_rows",
            "smc_build_planes", "smc_build_max_depth", "smc_mem_alloc", "smc_mem_free", "smc_mem_h2d", "smc_mem_d2h",
+           "smc_mem_alloc_host", "smc_mem_free_host",
            "smc_device_sync")
 
 
@@ -72,6 +73,9 @@ def load(with_torch: bool = True):
     L.smc_mem_alloc.argtypes = [vp, i64, ctypes.POINTER(vp)]
     L.smc_mem_free.argtypes = [vp, vp]
     L.smc_mem_free.restype = None
+    L.smc_mem_alloc_host.argtypes = [vp, i64, ctypes.POINTER(vp)]
+    L.smc_mem_free_host.argtypes = [vp, vp]
+    L.smc_mem_free_host.restype = None
     L.smc_mem_h2d.argtypes = [vp, vp, vp, i64]
     L.smc_mem_d2h.argtypes = [vp, vp, vp, i64]
     L.smc_device_sync.argtypes = [vp]

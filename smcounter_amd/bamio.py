@@ -629,20 +629,22 @@ class NativeBam(object):
                 k += int(n_keys[l])
         return tables
 
-    def alignments_run(self, chrom: str, lo: int, hi: int, max_reads: int, params, nthreads: int):
+    def alignments_run(self, chrom: str, lo: int, hi: int, max_reads: int, params, nthreads: int, host_array=None):
         """Host half of the device plane builder (smc_bam_alignments): the run's alignments as a structure of arrays -
         dict(aln, cig, seq, qual, loc, nl, n_slots, n_bc, n_pair, status, reads).  The handle keeps the run's records:
-        `allele_key` / `barcode_name` refer to them until the next call."""
+        `allele_key` / `barcode_name` refer to them until the next call.  `host_array(name, dtype, count)` (optional)
+        provides the arrays (engine.Engine.pinned: page-locked staging memory, reused from run to run)."""
         import ctypes as C
         from .abi import DEV_ALN_DTYPE, DEV_LOCUS_DTYPE
         got = {}
+        mk = host_array or (lambda name, dtype, count: np.empty(count, dtype))
 
         def alloc(ctx, n_aln, n_cig, n_seq, n_loci, out):
-            got["aln"] = np.empty(n_aln, DEV_ALN_DTYPE)
-            got["cig"] = np.empty(max(1, n_cig), np.uint32)
-            got["seq"] = np.empty(max(1, n_seq), np.uint8)
-            got["qual"] = np.empty(max(1, n_seq), np.uint8)
-            got["loc"] = np.empty(n_loci, DEV_LOCUS_DTYPE)
+            got["aln"] = mk("aln", DEV_ALN_DTYPE, n_aln)
+            got["cig"] = mk("cig", np.uint32, max(1, n_cig))
+            got["seq"] = mk("seq", np.uint8, max(1, n_seq))
+            got["qual"] = mk("qual", np.uint8, max(1, n_seq))
+            got["loc"] = mk("loc", DEV_LOCUS_DTYPE, n_loci)
             for k, name in enumerate(("aln", "cig", "seq", "qual", "loc")):
                 out[k] = got[name].ctypes.data
         cb = _ALN_ALLOC(alloc)

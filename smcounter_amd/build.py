@@ -77,7 +77,7 @@ def build_rowfmt(force: bool = False) -> str:
     hdr = os.path.join(ROOT, "include", "smcounter_hip.h")
     if force or not os.path.exists(ROWFMT_LIB) or \
             max(os.path.getmtime(ROWFMT_SRC), os.path.getmtime(hdr)) > os.path.getmtime(ROWFMT_LIB):
-        subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off",
+        subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-pthread",
                                "-I" + os.path.join(ROOT, "include"), "-o", ROWFMT_LIB, ROWFMT_SRC])
     return ROWFMT_LIB
 

@@ -59,7 +59,7 @@ def call_shard(args, params: VcParams, loci, device: int):
     from .engine import Engine
     ref = fasta.FastaFile(args.refGenome)
     eng = Engine(device)
-    output = []
+    output = _Rows()
     decoder = os.environ.get("SMC_BAM_DECODER", "native")
     # (one process per GPU: the ranks of a node share its cores for decoding)
     # (LOCAL_WORLD_SIZE: WORLD_SIZE also counts the ranks of other nodes, which do not share these cores)
@@ -77,13 +77,33 @@ def call_shard(args, params: VcParams, loci, device: int):
         batches = devplanes.iter_resident_batches(args.bamFile, ref, loci, params, eng, max_reads=8 * args.batchReads,
                                                   nthreads=nthreads)
         for first, rb in batches:
-            output.extend(vc.vc_resident(rb, params, ref, eng))
+            output.add(vc.vc_resident(rb, params, ref, eng))
         eng.close()
-        return output
+        return output.done()
     for first, pb in _prefetch(batches):
-        output.extend(vc.vc_batch(pb, params, ref, eng=eng))
+        output.add(vc.vc_batch(pb, params, ref, eng=eng))
     eng.close()
-    return output
+    return output.done()
+
+
+class _Rows(list):
+    """The shard's row strings; keeps the native printer's per-row int(PI) (rows.RowLines.pred) alongside when every batch
+    came with one, for the post-filter and the writers."""
+    pred = None
+
+    def __init__(self):
+        super().__init__()
+        self._parts = []
+
+    def add(self, part):
+        self.extend(part)
+        self._parts.append(getattr(part, "pred", None))
+
+    def done(self):
+        if self._parts and all(p is not None for p in self._parts):
+            import numpy as np
+            self.pred = np.concatenate(self._parts)
+        return self
 
 
 def _prefetch(it, depth: int = 2):
@@ -114,6 +134,19 @@ def _prefetch(it, depth: int = 2):
 def main(args) -> int:
     """Same contract as the reference's main(args): accepts a Namespace or a dict of argument values,
     returns the PI threshold used (smCounter.py:909)."""
+    # The run builds a few long lists of strings and no reference cycles: the cyclic collector would only rescan them, again
+    # and again (several milliseconds per 20,000 loci).  Off for the duration of the call.
+    import gc
+    gc_was_on = gc.isenabled()
+    gc.disable()
+    try:
+        return _main(args)
+    finally:
+        if gc_was_on:
+            gc.enable()
+
+
+def _main(args) -> int:
     t0 = datetime.datetime.now()
     print("smCounter started at " + str(t0))
     parser = build_parser()
@@ -181,9 +214,10 @@ def main(args) -> int:
         args.bedTarget,
         args.bedTandemRepeats if args.bedTandemRepeats and os.path.exists(args.bedTandemRepeats) else None,
         args.bedRepeatMaskerSubset if args.bedRepeatMaskerSubset and os.path.exists(args.bedRepeatMaskerSubset) else None)
-    output = postfilter.apply_repeat_filters(output, trf, rm)
+    pred = getattr(output, "pred", None)                  # (single process: the printer's int(PI) per row)
+    output = postfilter.apply_repeat_filters(output, trf, rm, pred=pred)
     threshold = writers.pi_threshold(args.mtDepth, args.threshold)
-    writers.write_outputs(args.outPrefix, output, threshold)
+    writers.write_outputs(args.outPrefix, output, threshold, pred=pred)
     t1 = datetime.datetime.now()
     print("smCounter completed running at " + str(t1))
     print("smCounter total time: " + str(t1 - t0))

@@ -16,8 +16,13 @@
 
 #include "smcounter_hip.h"   // smc_locus: the descriptor smc_bam_planes fills
 
+#include <unistd.h>
+
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <string_view>
 #include <thread>
@@ -27,6 +32,122 @@
 namespace {
 
 const char SEQ_CODE[] = "=ACMGRSVTWYHKDBN";
+
+// Worker threads shared by every stage of a decode (inflate, parse, interning, packing): started once per process and
+// reused, because a run's stages are each a millisecond or two of work and starting a hundred threads per stage costs
+// more than that.  run(n, f) executes f(0) .. f(n - 1), the caller taking part; tasks are claimed one by one.
+class Pool {
+    std::vector<std::thread>* th = new std::vector<std::thread>();   // (a pointer: dropped, not destroyed, in a forked child)
+    std::mutex m;
+    std::condition_variable cv, cv_done;
+    const std::function<void(int)>* job = nullptr;
+    int n_tasks = 0, busy = 0, invited = 0;
+    std::atomic<int> next{0};
+    std::atomic<uint64_t> gen_hint{0};
+    static void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+    }
+    uint64_t gen = 0;
+    bool stop = false;
+    pid_t owner = 0;
+    void worker(int id) {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(int)>* f;
+            // a decode is a chain of short stages: a worker that just finished one spins briefly for the next before it sleeps
+            for (int spin = 0; spin < 2000 && gen_hint.load(std::memory_order_relaxed) == seen; ++spin) cpu_relax();
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return stop || (gen != seen && id < invited); });
+                if (stop) return;
+                seen = gen; f = job;
+                ++busy;
+            }
+            for (int i = next.fetch_add(1); i < n_tasks; i = next.fetch_add(1)) (*f)(i);
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (--busy == 0) cv_done.notify_all();
+            }
+        }
+    }
+public:
+    static Pool& get() { static Pool* p = new Pool; return *p; }   // (never destroyed: no join at exit)
+    // at most `par` threads (incl. the caller) work on the n tasks
+    void run(int n, int par, const std::function<void(int)>& f) {
+        if (n <= 0) return;
+        par = std::min(par, n);
+        if (par <= 1) { for (int i = 0; i < n; ++i) f(i); return; }
+        std::unique_lock<std::mutex> lk(m);
+        if (owner != getpid()) { if (owner) th = new std::vector<std::thread>(); owner = getpid(); busy = 0; }
+        while ((int)th->size() < par - 1 && th->size() < 255) { const int id = (int)th->size(); th->emplace_back([this, id] { worker(id); }); }
+        job = &f; n_tasks = n; next.store(0); invited = par - 1; ++gen;
+        gen_hint.store(gen, std::memory_order_relaxed);
+        lk.unlock();
+        cv.notify_all();
+        for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) f(i);
+        lk.lock();
+        // every invited worker has either finished or not yet looked: un-invite the latecomers, wait for the busy ones
+        invited = 0;
+        cv_done.wait(lk, [&] { return busy == 0; });
+        job = nullptr;
+    }
+};
+
+// Grow-only byte buffer without value initialisation (a std::vector would zero - and page in - tens of megabytes per run
+// on one thread; here the inflating threads touch the pages first, and the memory is reused from run to run).
+struct ByteBuf {
+    uint8_t* p = nullptr;
+    size_t n = 0, cap = 0;
+    ByteBuf() = default;
+    ByteBuf(const ByteBuf&) = delete;
+    ByteBuf& operator=(const ByteBuf&) = delete;
+    ~ByteBuf() { free(p); }
+    uint8_t* data() { return p; }
+    const uint8_t* data() const { return p; }
+    size_t size() const { return n; }
+    bool resize(size_t want) {                       // contents up to min(old, new) size are kept
+        if (want > cap) {
+            size_t c = cap ? cap : (1u << 20);
+            while (c < want) c += c / 2;
+            uint8_t* q = (uint8_t*)realloc(p, c);
+            if (!q) return false;
+            p = q; cap = c;
+        }
+        n = want;
+        return true;
+    }
+    void swap(ByteBuf& o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); }
+};
+// The same for arrays of trivially copyable records (the run's alignments: ~ 120 bytes each, all fields written by the parser)
+template <class T> struct RawVec {
+    T* p = nullptr;
+    size_t n = 0, cap = 0;
+    RawVec() = default;
+    RawVec(const RawVec&) = delete;
+    RawVec& operator=(const RawVec&) = delete;
+    ~RawVec() { free(p); }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    T& operator[](size_t i) { return p[i]; }
+    const T& operator[](size_t i) const { return p[i]; }
+    T* begin() { return p; }
+    T* end() { return p + n; }
+    const T* begin() const { return p; }
+    const T* end() const { return p + n; }
+    void clear() { n = 0; }
+    void resize_uninit(size_t want) {                // (old contents kept; aborts like operator new on exhaustion)
+        if (want > cap) {
+            size_t c = cap ? cap : 4096;
+            while (c < want) c += c / 2;
+            T* q = (T*)realloc((void*)p, c * sizeof(T));
+            if (!q) abort();
+            p = q; cap = c;
+        }
+        n = want;
+    }
+};
 
 // Views into the inflated record bytes (kept in Bam::rec_data until the next run): an alignment owns no memory, so
 // parsing copies nothing and dropping a run's alignments frees nothing.
@@ -80,7 +201,8 @@ struct Bam {
     FILE* fh = nullptr;
     std::string err;
     int io_threads = 1;                // threads inflating BGZF blocks in collect_reads
-    std::vector<uint8_t> rec_data;     // inflated records of the last collect_reads (its alignments point into it)
+    ByteBuf rec_data;                  // inflated records of the last collect_reads (its alignments point into it)
+    ByteBuf comp;                      // compressed bytes of the blocks being inflated (reused)
     // streaming cursor: where the previous collect_reads found its first overlapping record - a later run on the
     // same reference that starts at or after the previous one never needs anything before it
     int cur_tid = -1;
@@ -105,7 +227,8 @@ struct Bam {
     std::vector<uint32_t> p_umi_start;
     std::string ds_info;               // loci over the barcode cap: "<locus>\t<u>:<barcode>\t...\n", barcodes by first included read
     // last smc_bam_alignments result: the run's alignments (views into rec_data) and its barcode texts by run-wide id
-    std::vector<Aln> d_reads;
+    RawVec<Aln> d_reads;
+    RawVec<Aln> parsed;                // (scratch of collect_reads, reused)
     std::vector<std::string> d_bc_names;
 
     bool load_block(uint64_t coff) {
@@ -226,85 +349,103 @@ struct Libdeflate {
 };
 static const Libdeflate g_ld;
 
-// Record stream over consecutive BGZF blocks starting at a virtual offset: blocks are read from the file in
-// batches and inflated by `nthreads` threads (each block is an independent deflate stream), records are then
-// parsed in place.
+// Record stream over consecutive BGZF blocks starting at a virtual offset: a stretch of the file is read in one piece,
+// its blocks (independent deflate streams) are inflated by the pool into one growing buffer, records are then parsed in
+// place.  Consumed bytes are kept (record offsets stay valid for the whole run).
 struct BlockStream {
     Bam& b;
     int nthreads;
     uint64_t next_coff;
-    std::vector<uint8_t> data;     // inflated bytes not yet consumed, from `pos`
+    ByteBuf data;                  // inflated bytes, consumed up to `pos`
     size_t pos = 0;
     bool eof = false;
-    bool keep = false;             // keep consumed bytes (record offsets stay valid)
-    std::vector<std::pair<size_t, uint64_t>> blocks;   // keep mode: (offset in data, file offset) of every block
+    std::vector<std::pair<size_t, uint64_t>> blocks;   // (offset in data, file offset) of every block
     uint64_t soft_stop = ~0ull;    // hint: file offset beyond which the caller expects to need (almost) nothing
-    BlockStream(Bam& bam, uint64_t voff, int nt, bool keep_all = false, uint64_t stop_hint = ~0ull)
-        : b(bam), nthreads(nt < 1 ? 1 : nt), next_coff(voff >> 16), keep(keep_all), soft_stop(stop_hint) {
+    BlockStream(Bam& bam, uint64_t voff, int nt, uint64_t stop_hint = ~0ull)
+        : b(bam), nthreads(nt < 1 ? 1 : nt), next_coff(voff >> 16), soft_stop(stop_hint) {
+        data.swap(b.rec_data);     // (the previous run's buffer: its pages are already there)
+        data.n = 0;
         refill();
         pos = (size_t)(voff & 0xFFFF);
         if (pos > data.size()) pos = data.size();
     }
     bool refill() {
         if (eof) return false;
-        if (!keep) { data.erase(data.begin(), data.begin() + (long)pos); pos = 0; }
-        const int batch = nthreads > 1 ? 8 * nthreads : 4;
-        struct Raw { std::vector<uint8_t> comp; size_t c0, clen; uint32_t isize; size_t out_off; };
-        std::vector<Raw> raws;
-        if (fseeko(b.fh, (off_t)next_coff, SEEK_SET) != 0) { eof = true; return false; }
-        size_t total = 0;
-        int past = 0;
-        for (int k = 0; k < batch; ++k) {
-            uint8_t hdr[18];
-            if (fread(hdr, 1, 18, b.fh) != 18) { eof = true; break; }
-            if (hdr[0] != 31 || hdr[1] != 139 || hdr[12] != 'B' || hdr[13] != 'C') { b.err = "not a BGZF block"; eof = true; break; }
-            const unsigned xlen = hdr[10] | (hdr[11] << 8), bsize = (hdr[16] | (hdr[17] << 8)) + 1;
-            Raw r;
-            r.comp.resize(bsize - 18);
-            if (fread(r.comp.data(), 1, r.comp.size(), b.fh) != r.comp.size()) { b.err = "truncated BGZF block"; eof = true; break; }
-            r.c0 = xlen - 6; r.clen = r.comp.size() - r.c0 - 8;
-            const size_t e = r.comp.size();
-            r.isize = r.comp[e - 4] | (r.comp[e - 3] << 8) | (r.comp[e - 2] << 16) | ((uint32_t)r.comp[e - 1] << 24);
-            r.out_off = total; total += r.isize;
-            if (keep) blocks.emplace_back(data.size() + r.out_off, next_coff);
-            next_coff += bsize;
-            raws.push_back(std::move(r));
-            if (next_coff > soft_stop && ++past >= 2) break;      // (a hint only: the caller refills again if it must)
+        // the stretch to read: up to two blocks behind the hint, or 8 MB when there is none (the caller refills again if it must)
+        size_t want = 8u << 20;
+        if (soft_stop != ~0ull) want = soft_stop > next_coff ? (size_t)(soft_stop - next_coff) + (3u << 16) : (3u << 16);
+        // (no further per refill than the threads can share: a consumer that finds its last record early stops refilling)
+        want = std::min<size_t>(want, std::max<size_t>(1u << 20, (size_t)nthreads << 16));
+        want = std::min<size_t>(std::max<size_t>(want, 1u << 18), 256u << 20);
+        const auto tr0 = std::chrono::steady_clock::now();
+        if (!b.comp.resize(want)) { b.err = "out of memory"; eof = true; return false; }
+        size_t got = 0;
+        while (got < want) {
+            const ssize_t r = pread(fileno(b.fh), b.comp.data() + got, want - got, (off_t)(next_coff + got));
+            if (r <= 0) break;
+            got += (size_t)r;
         }
-        if (raws.empty()) return false;
+        struct Blk { size_t c0, clen; uint32_t isize; size_t out_off; };
+        std::vector<Blk> blks;
+        size_t o = 0, total = 0;
+        int past = 0;
+        const uint8_t* cb = b.comp.data();
+        while (o + 18 <= got) {
+            const uint8_t* hdr = cb + o;
+            if (hdr[0] != 31 || hdr[1] != 139 || hdr[12] != 'B' || hdr[13] != 'C') { b.err = "not a BGZF block"; eof = true; break; }
+            const size_t xlen = hdr[10] | (hdr[11] << 8), bsize = (size_t)(hdr[16] | (hdr[17] << 8)) + 1;
+            if (bsize < 12 + xlen + 8) { b.err = "not a BGZF block"; eof = true; break; }
+            if (o + bsize > got) break;                                 // cut by the end of the stretch: next refill
+            Blk k;
+            k.c0 = o + 12 + xlen; k.clen = bsize - 12 - xlen - 8;
+            const uint8_t* tl = cb + o + bsize - 4;
+            k.isize = tl[0] | (tl[1] << 8) | (tl[2] << 16) | ((uint32_t)tl[3] << 24);
+            k.out_off = total; total += k.isize;
+            blocks.emplace_back(data.size() + k.out_off, next_coff + o);
+            blks.push_back(k);
+            o += bsize;
+            if (next_coff + o > soft_stop && ++past >= 2) break;
+        }
+        if (blks.empty()) {
+            if (b.err.empty() && got >= 18 && o + 18 <= got && got == want && want < (256u << 20)) { b.err = "BGZF block larger than the read window"; }
+            else if (b.err.empty() && got > o && got < want) b.err = "truncated BGZF block";
+            eof = true;
+            return false;
+        }
+        next_coff += o;
+        const auto tr1 = std::chrono::steady_clock::now();
+        t_read += std::chrono::duration<double, std::milli>(tr1 - tr0).count();
         const size_t base = data.size();
-        data.resize(base + total);
-        std::atomic<int> bad(0), next(0);
-        auto work = [&]() {
+        if (!data.resize(base + total)) { b.err = "out of memory"; eof = true; return false; }
+        std::atomic<int> bad(0);
+        uint8_t* const out = data.data() + base;
+        // tasks of ~4 blocks (a block inflates in 20-200 us)
+        const int per = 4, nt = ((int)blks.size() + per - 1) / per;
+        Pool::get().run(nt, nthreads, [&](int t) {
             void* ld = g_ld.ok() ? g_ld.alloc() : nullptr;
-            for (int i = next.fetch_add(1); i < (int)raws.size(); i = next.fetch_add(1)) {
-                Raw& r = raws[(size_t)i];
-                if (!r.isize) continue;
+            for (int i = t * per; i < std::min<int>((t + 1) * per, (int)blks.size()); ++i) {
+                const Blk& k = blks[(size_t)i];
+                if (!k.isize) continue;
                 if (ld) {
-                    size_t got = 0;
-                    if (g_ld.decompress(ld, r.comp.data() + r.c0, r.clen, data.data() + base + r.out_off, r.isize, &got) != 0 || got != r.isize) bad = 1;
+                    size_t n = 0;
+                    if (g_ld.decompress(ld, cb + k.c0, k.clen, out + k.out_off, k.isize, &n) != 0 || n != k.isize) bad = 1;
                     continue;
                 }
                 z_stream zs;
                 memset(&zs, 0, sizeof zs);
                 if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; continue; }
-                zs.next_in = r.comp.data() + r.c0; zs.avail_in = (uInt)r.clen;
-                zs.next_out = data.data() + base + r.out_off; zs.avail_out = r.isize;
+                zs.next_in = const_cast<uint8_t*>(cb + k.c0); zs.avail_in = (uInt)k.clen;
+                zs.next_out = out + k.out_off; zs.avail_out = k.isize;
                 if (inflate(&zs, Z_FINISH) != Z_STREAM_END) bad = 1;
                 inflateEnd(&zs);
             }
             if (ld) g_ld.release(ld);
-        };
-        const int T = std::min<int>(nthreads, ((int)raws.size() + 3) / 4);   // >= 4 blocks (~1 ms) per thread started
-        if (T <= 1) work();
-        else {
-            std::vector<std::thread> th;
-            for (int t = 0; t < T; ++t) th.emplace_back(work);
-            for (auto& x : th) x.join();
-        }
+        });
+        t_inflate += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr1).count();
         if (bad.load()) { b.err = "inflate failed"; eof = true; return false; }
         return true;
     }
+    double t_read = 0, t_inflate = 0;   // ms, for SMC_BAM_TIMING
     // BAM virtual offset of the byte at data offset `o` (keep mode)
     uint64_t voffset_of(size_t o) const {
         size_t lo = 0, hi = blocks.size();
@@ -326,7 +467,7 @@ struct BlockStream {
 
 // Mapped alignments overlapping [start0, end0) on `chrom`, in file order, with run-wide barcode / fragment ids
 // and the per-read CIGAR summaries.  Returns 0, or the negative error code of smc_bam_pileup.
-int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::vector<Aln>& reads, int& n_bc, int& n_pair,
+int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, RawVec<Aln>& reads, int& n_bc, int& n_pair,
                   std::vector<std::string>* bc_names = nullptr) {
     int tid = -1;
     for (size_t i = 0; i < b.ref_names.size(); ++i) if (b.ref_names[i] == chrom) tid = (int)i;
@@ -353,7 +494,7 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::
         }
         // 1. inflate (threads) and find the record boundaries up to the first alignment starting at or after end0
         const auto tc0 = std::chrono::steady_clock::now();
-        BlockStream bs(b, voff, b.io_threads, true, stop_hint);
+        BlockStream bs(b, voff, b.io_threads, stop_hint);
         std::vector<std::pair<size_t, size_t>> recs;    // (offset of the body in bs.data, size)
         for (;;) {
             size_t rn;
@@ -366,13 +507,14 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::
             recs.emplace_back((size_t)(rp - bs.data.data()), rn);
         }
         // (the alignments are views into the inflated bytes: those move into the handle and live until the next run)
-        b.rec_data = std::move(bs.data);
+        b.rec_data.swap(bs.data);
         const uint8_t* const rec_base = b.rec_data.data();
         // 2. parse them (threads), 3. filter and intern barcode / read ids in file order
         const auto tc1 = std::chrono::steady_clock::now();
-        std::vector<Aln> parsed(recs.size());
+        RawVec<Aln>& parsed = b.parsed;
+        parsed.resize_uninit(recs.size());
         {
-            const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)b.io_threads, recs.size() / 2048 + 1));
+            const int T = (int)(recs.size() / 1024 + 1);            // tasks of ~1024 records
             auto work = [&](int t) {
                 const size_t lo = recs.size() * (size_t)t / (size_t)T, hi = recs.size() * (size_t)(t + 1) / (size_t)T;
                 int32_t rt;
@@ -403,12 +545,7 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::
                     a.oflag = (uint8_t)(((a.flag & 0x40) ? 1 : 0) | ((a.flag & 0x80) ? 2 : 0) | ((a.flag & 0x10) ? 4 : 0) | (a.has_nm ? 8 : 0));
                 }
             };
-            if (T == 1) work(0);
-            else {
-                std::vector<std::thread> th;
-                for (int t = 0; t < T; ++t) th.emplace_back(work, t);
-                for (auto& x : th) x.join();
-            }
+            Pool::get().run(T, b.io_threads, work);
         }
         const auto tc2 = std::chrono::steady_clock::now();
         bool have_first = false, have_end = false;
@@ -437,11 +574,55 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::
         // (memcmp) and a colliding hash resolved through a string map.  Sharded by hash over the threads: a shard owns its
         // hashes, so ids are dense and exact whatever the thread count (they number DISTINCT strings; nothing downstream
         // depends on their order: first-appearance numbering happens per locus).
+        const auto tc2b = std::chrono::steady_clock::now();
         int SH = 1;
-        while (SH < 16 && SH * 2 <= b.io_threads && (size_t)SH * 8192 < n_keep) SH *= 2;
-        if (const char* e = getenv("SMC_BAM_SHARDS")) { SH = 1; while (SH < 16 && SH * 2 <= atoi(e)) SH *= 2; }   // (tests)
+        while (SH < 64 && SH * 2 <= b.io_threads && (size_t)SH * 2048 < n_keep) SH *= 2;
+        if (const char* e = getenv("SMC_BAM_SHARDS")) { SH = 1; while (SH < 64 && SH * 2 <= atoi(e)) SH *= 2; }   // (tests)
+        // the kept records are first binned by shard (stretches of the file in parallel, a bin per stretch and shard; a
+        // shard then walks its bins stretch by stretch, i.e. in file order) so that a shard touches only its own records
+        const int NB = SH == 1 ? 1 : (int)std::min<size_t>(256, parsed.size() / 2048 + 1);
+        std::vector<std::vector<uint32_t>> bins_bc((size_t)NB * (size_t)SH), bins_pair((size_t)NB * (size_t)SH);
+        if (SH > 1) {
+            const uint64_t msk = (uint64_t)SH - 1;
+            Pool::get().run(NB, b.io_threads, [&](int c) {
+                const size_t lo = parsed.size() * (size_t)c / (size_t)NB, hi = parsed.size() * (size_t)(c + 1) / (size_t)NB;
+                for (size_t pi = lo; pi < hi; ++pi) {
+                    if (!keep[pi]) continue;
+                    bins_bc[(size_t)c * SH + (size_t)((parsed[pi].h_bc >> 20) & msk)].push_back((uint32_t)pi);
+                    bins_pair[(size_t)c * SH + (size_t)((parsed[pi].h_pair >> 20) & msk)].push_back((uint32_t)pi);
+                }
+            });
+        }
+        // open-addressing table hash -> id (linear probing, grows at half load): one allocation, nothing to free node by node
+        struct FlatMap {
+            std::vector<uint64_t> key;
+            std::vector<int> val;                                       // -1: empty
+            size_t mask = 0, used = 0;
+            void init(size_t expect) {
+                size_t c = 64;
+                while (c < 2 * expect) c <<= 1;
+                key.assign(c, 0); val.assign(c, -1); mask = c - 1; used = 0;
+            }
+            int* find(uint64_t k) {
+                for (size_t i = (size_t)(k * 0x9E3779B97F4A7C15ull >> 20) & mask;; i = (i + 1) & mask) {
+                    if (val[i] < 0) return nullptr;
+                    if (key[i] == k) return &val[i];
+                }
+            }
+            void emplace(uint64_t k, int v) {
+                if (2 * (used + 1) > mask + 1) {
+                    std::vector<uint64_t> ok; std::vector<int> ov;
+                    ok.swap(key); ov.swap(val);
+                    init(ok.size());
+                    for (size_t i = 0; i < ok.size(); ++i) if (ov[i] >= 0) emplace(ok[i], ov[i]);
+                }
+                size_t i = (size_t)(k * 0x9E3779B97F4A7C15ull >> 20) & mask;
+                while (val[i] >= 0) i = (i + 1) & mask;
+                key[i] = k; val[i] = v; ++used;
+            }
+        };
         struct Shard {
-            std::unordered_map<uint64_t, int> hb, hp;
+            FlatMap hb, hp;
             std::vector<size_t> bc_rep, pair_rep;                       // index into `parsed` of the id's first record
             std::unordered_map<std::string, int> bc_str, pair_str;     // only for colliding hashes
         };
@@ -451,44 +632,55 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::
         };
         auto intern = [&](int t) {
             Shard& S = shards[(size_t)t];
-            const uint64_t msk = (uint64_t)SH - 1;
-            for (size_t pi = 0; pi < parsed.size(); ++pi) {
-                if (!keep[pi]) continue;
+            {
+                // (barcodes: a few reads each at least; read names: two alignments each, typically)
+                size_t mine = 0;
+                if (SH == 1) mine = n_keep;
+                else for (int c = 0; c < NB; ++c) mine += bins_pair[(size_t)c * SH + (size_t)t].size();
+                S.hb.init(mine / 8 + 64); S.hp.init(mine / 2 + 64);
+            }
+            auto do_bc = [&](size_t pi) {
                 Aln& a = parsed[pi];
                 const std::string_view qn = a.qname;
                 const size_t c1 = (size_t)a.c1, c2 = (size_t)a.c2;
-                if (((a.h_bc >> 20) & msk) == (uint64_t)t) {
-                    auto it = S.hb.find(a.h_bc);
-                    if (it != S.hb.end() && bc_equal(parsed[S.bc_rep[(size_t)it->second]], a)) a.bc_gid = it->second;
-                    else if (it == S.hb.end()) { a.bc_gid = (int)S.bc_rep.size(); S.hb.emplace(a.h_bc, a.bc_gid); S.bc_rep.push_back(pi); }
+                {
+                    const int* it = S.hb.find(a.h_bc);
+                    if (it && bc_equal(parsed[S.bc_rep[(size_t)*it]], a)) a.bc_gid = *it;
+                    else if (!it) { a.bc_gid = (int)S.bc_rep.size(); S.hb.emplace(a.h_bc, a.bc_gid); S.bc_rep.push_back(pi); }
                     else {                                   // hash collision: the string decides
                         auto r = S.bc_str.emplace(std::string(qn.substr(c2 + 1, c1 - c2 - 1)), (int)S.bc_rep.size());
                         if (r.second) S.bc_rep.push_back(pi);
                         a.bc_gid = r.first->second;
                     }
                 }
-                if (((a.h_pair >> 20) & msk) == (uint64_t)t) {
-                    auto it = S.hp.find(a.h_pair);
-                    const bool hit = it != S.hp.end() && [&] {
-                        const Aln& o = parsed[S.pair_rep[(size_t)it->second]];
+            };
+            auto do_pair = [&](size_t pi) {
+                Aln& a = parsed[pi];
+                const std::string_view qn = a.qname;
+                const size_t c1 = (size_t)a.c1, c2 = (size_t)a.c2;
+                {
+                    const int* it = S.hp.find(a.h_pair);
+                    const bool hit = it && [&] {
+                        const Aln& o = parsed[S.pair_rep[(size_t)*it]];
                         return o.c2 == a.c2 && bc_equal(o, a) && memcmp(o.qname.data(), qn.data(), c2) == 0;
                     }();
-                    if (hit) a.pair_gid = it->second;
-                    else if (it == S.hp.end()) { a.pair_gid = (int)S.pair_rep.size(); S.hp.emplace(a.h_pair, a.pair_gid); S.pair_rep.push_back(pi); }
+                    if (hit) a.pair_gid = *it;
+                    else if (!it) { a.pair_gid = (int)S.pair_rep.size(); S.hp.emplace(a.h_pair, a.pair_gid); S.pair_rep.push_back(pi); }
                     else {
                         auto r = S.pair_str.emplace(std::string(qn.substr(c2 + 1, c1 - c2 - 1)) + "\x01" + std::string(qn.substr(0, c2)), (int)S.pair_rep.size());
                         if (r.second) S.pair_rep.push_back(pi);
                         a.pair_gid = r.first->second;
                     }
                 }
+            };
+            if (SH == 1) {
+                for (size_t pi = 0; pi < parsed.size(); ++pi) if (keep[pi]) { do_bc(pi); do_pair(pi); }
+                return;
             }
+            for (int c = 0; c < NB; ++c) for (uint32_t pi : bins_bc[(size_t)c * SH + (size_t)t]) do_bc(pi);
+            for (int c = 0; c < NB; ++c) for (uint32_t pi : bins_pair[(size_t)c * SH + (size_t)t]) do_pair(pi);
         };
-        if (SH == 1) intern(0);
-        else {
-            std::vector<std::thread> th;
-            for (int t = 0; t < SH; ++t) th.emplace_back(intern, t);
-            for (auto& x : th) x.join();
-        }
+        Pool::get().run(SH, b.io_threads, intern);
         std::vector<int> bc_off((size_t)SH + 1, 0), pair_off((size_t)SH + 1, 0);
         for (int t = 0; t < SH; ++t) {
             bc_off[(size_t)t + 1] = bc_off[(size_t)t] + (int)shards[(size_t)t].bc_rep.size();
@@ -502,16 +694,31 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::
                     (*bc_names)[(size_t)bc_off[(size_t)t] + k] = std::string(o.qname.substr((size_t)o.c2 + 1, (size_t)(o.c1 - o.c2 - 1)));
                 }
         }
-        reads.reserve(n_keep);
+        const auto tc2c = std::chrono::steady_clock::now();
         {
+            // the kept records, in file order, with the shard-local ids made run-wide (stretches in parallel)
             const uint64_t msk = (uint64_t)SH - 1;
-            for (size_t pi = 0; pi < parsed.size(); ++pi) {
-                if (!keep[pi]) continue;
-                Aln& a = parsed[pi];
-                a.bc_gid += bc_off[(size_t)((a.h_bc >> 20) & msk)];
-                a.pair_gid += pair_off[(size_t)((a.h_pair >> 20) & msk)];
-                reads.push_back(std::move(a));
+            const int NC = (int)std::min<size_t>(256, parsed.size() / 4096 + 1);
+            std::vector<size_t> first((size_t)NC + 1, 0);
+            for (int c = 0; c < NC; ++c) {
+                const size_t lo = parsed.size() * (size_t)c / (size_t)NC, hi = parsed.size() * (size_t)(c + 1) / (size_t)NC;
+                size_t k = 0;
+                for (size_t pi = lo; pi < hi; ++pi) k += keep[pi];
+                first[(size_t)c + 1] = first[(size_t)c] + k;
             }
+            const size_t base = reads.size();
+            reads.resize_uninit(base + n_keep);
+            Pool::get().run(NC, b.io_threads, [&](int c) {
+                const size_t lo = parsed.size() * (size_t)c / (size_t)NC, hi = parsed.size() * (size_t)(c + 1) / (size_t)NC;
+                size_t o = base + first[(size_t)c];
+                for (size_t pi = lo; pi < hi; ++pi) {
+                    if (!keep[pi]) continue;
+                    Aln& a = parsed[pi];
+                    a.bc_gid += bc_off[(size_t)((a.h_bc >> 20) & msk)];
+                    a.pair_gid += pair_off[(size_t)((a.h_pair >> 20) & msk)];
+                    reads[o++] = a;
+                }
+            });
         }
         const std::vector<int>& bc_rep = bc_off; const std::vector<int>& pair_rep = pair_off;    // (sizes below)
         n_bc = bc_off[(size_t)SH]; n_pair = pair_off[(size_t)SH];
@@ -519,8 +726,8 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, std::
         if (getenv("SMC_BAM_TIMING")) {
             const auto tc3 = std::chrono::steady_clock::now();
             auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-            fprintf(stderr, "collect_reads: %zu records, %zu kept: inflate + boundaries %.1f ms, parse %.1f ms, intern %.1f ms (%zu KB inflated)\n",
-                    recs.size(), reads.size(), ms(tc0, tc1), ms(tc1, tc2), ms(tc2, tc3), b.rec_data.size() >> 10);
+            fprintf(stderr, "collect_reads: %zu records, %zu kept: inflate + boundaries %.1f ms (read %.1f, inflate %.1f), parse %.1f ms, keep %.1f ms, intern %.1f ms, gather %.1f ms (%zu KB inflated, %d shards)\n",
+                    recs.size(), reads.size(), ms(tc0, tc1), bs.t_read, bs.t_inflate, ms(tc1, tc2), ms(tc2, tc2b), ms(tc2b, tc2c), ms(tc2c, tc3), b.rec_data.size() >> 10, SH);
         }
         if (!have_first) { b.cur_tid = tid; b.cur_start = start0; b.cur_voff = recs.empty() ? voff : bs.voffset_of(recs.back().first - 4); }
         if (!b.err.empty()) return -2;                  // corrupt / truncated BGZF
@@ -639,6 +846,10 @@ void smc_bam_close(void* h) {
     Bam* b = (Bam*)h;
     if (!b) return;
     if (b->fh) fclose(b->fh);
+    b->fh = nullptr;
+    // a handle that has decoded runs holds their buffers (tens to hundreds of megabytes): unmapping them takes
+    // milliseconds, which nobody has to wait for
+    if (b->rec_data.cap > (8u << 20)) { try { std::thread([b] { delete b; }).detach(); return; } catch (...) {} }
     delete b;
 }
 
@@ -657,7 +868,7 @@ int64_t smc_bam_pileup(void* h, const char* chrom, int64_t start0, int64_t end0,
     b.qpos.clear(); b.indel.clear(); b.flag.clear(); b.mq.clear(); b.is_del.clear(); b.allele.clear(); b.bq.clear();
     b.read_off.assign(1, 0); b.keys.clear(); b.n_keys.clear();
     *n_loci_done = 0;
-    std::vector<Aln> reads;
+    RawVec<Aln> reads;
     int n_bc = 0, n_pair = 0;
     { const int rc = collect_reads(b, chrom, start0, end0, reads, n_bc, n_pair); if (rc) return rc; }
     // per-locus dense ids through epoch-stamped tables over the run-wide ids
@@ -746,7 +957,7 @@ int64_t smc_bam_planes(void* h, const char* chrom, int64_t start0, int64_t end0,
     b.keys.clear(); b.n_keys.clear(); b.ds_info.clear();
     b.io_threads = nthreads;
     *n_loci_done = *n_slots = *n_umi_start = 0;
-    std::vector<Aln> reads;
+    RawVec<Aln> reads;
     int n_bc = 0, n_pair = 0;
     const auto t_0 = std::chrono::steady_clock::now();
     std::vector<std::string> bc_names;
@@ -945,16 +1156,23 @@ int64_t smc_bam_alignments(void* h, const char* chrom, int64_t start0, int64_t e
     *n_loci_done = *n_slots = 0; *status = 0;
     b.d_reads.clear(); b.d_bc_names.clear();
     int n_bc = 0, n_pair = 0;
+    const auto t_a0 = std::chrono::steady_clock::now();
     { const int rc = collect_reads(b, chrom, start0, end0, b.d_reads, n_bc, n_pair, &b.d_bc_names); if (rc) return rc; }
-    const std::vector<Aln>& reads = b.d_reads;
+    const auto t_a1 = std::chrono::steady_clock::now();
+    const RawVec<Aln>& reads = b.d_reads;
     const int64_t span = end0 - start0;
+    // one pass over the alignments: depth differences per position, and where each alignment's CIGAR words and bases go in the pools
     std::vector<int64_t> cov((size_t)span + 1, 0);
-    for (const Aln& a : reads) {
+    std::vector<uint32_t> offc(reads.size() + 1, 0), offs(reads.size() + 1, 0);
+    for (size_t i = 0; i < reads.size(); ++i) {
+        const Aln& a = reads[i];
         const int64_t lo = std::max<int64_t>(a.pos, start0), hi = std::min<int64_t>(a.end, end0);
         if (lo < hi) { ++cov[(size_t)(lo - start0)]; --cov[(size_t)(hi - start0)]; }
+        offc[i + 1] = offc[i] + a.cigar.n; offs[i + 1] = offs[i] + a.l_seq;
     }
     int64_t nl = 0, total = 0, run = 0, slots = 0;
     std::vector<uint32_t> l_off, l_n;
+    l_off.reserve((size_t)span); l_n.reserve((size_t)span);
     for (int64_t k = 0; k < span; ++k) {
         run += cov[(size_t)k];
         total += run;
@@ -963,21 +1181,18 @@ int64_t smc_bam_alignments(void* h, const char* chrom, int64_t start0, int64_t e
         ++nl;
         if (total >= max_reads) break;
     }
-    int64_t n_cig = 0, n_seq = 0;
-    for (const Aln& a : reads) { n_cig += a.cigar.n; n_seq += a.l_seq; }
+    const int64_t n_cig = offc[reads.size()], n_seq = offs[reads.size()];
     void* bufs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     alloc(alloc_ctx, (int64_t)reads.size(), n_cig, n_seq, nl, bufs);
     smc_dev_aln* pa = (smc_dev_aln*)bufs[0]; uint32_t* pc = (uint32_t*)bufs[1];
     uint8_t* ps = (uint8_t*)bufs[2]; uint8_t* pq = (uint8_t*)bufs[3]; smc_dev_locus* pl = (smc_dev_locus*)bufs[4];
     if ((!reads.empty() && (!pa || !pc || !ps || !pq)) || (nl && !pl)) { b.err = "smc_bam_alignments: allocation callback returned no memory"; return -9; }
-    // offsets of every alignment's CIGAR words and bases in the pools, then the records and pools are filled by the threads
-    std::vector<uint32_t> offc(reads.size() + 1, 0), offs(reads.size() + 1, 0);
-    for (size_t i = 0; i < reads.size(); ++i) { offc[i + 1] = offc[i] + reads[i].cigar.n; offs[i + 1] = offs[i] + reads[i].l_seq; }
+    // the records and pools are filled by the threads
     std::atomic<int> st_bits(0);
     const auto t_p0 = std::chrono::steady_clock::now();
     {
         static const char* const CODE = "=ACMGRSVTWYHKDBN";
-        const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)nthreads, reads.size() / 4096 + 1));
+        const int T = (int)(reads.size() / 1024 + 1);
         auto work = [&](int t) {
             const size_t lo = reads.size() * (size_t)t / (size_t)T, hi = reads.size() * (size_t)(t + 1) / (size_t)T;
             int st = 0;
@@ -1006,17 +1221,10 @@ int64_t smc_bam_alignments(void* h, const char* chrom, int64_t start0, int64_t e
             }
             if (st) st_bits.fetch_or(st);
         };
-        if (T == 1) work(0);
-        else {
-            std::vector<std::thread> th;
-            for (int t = 0; t < T; ++t) th.emplace_back(work, t);
-            for (auto& x : th) x.join();
-        }
+        Pool::get().run(T, nthreads, work);
     }
     const int st = st_bits.load();
-    if (getenv("SMC_BAM_TIMING"))
-        fprintf(stderr, "smc_bam_alignments: %zu alignments, %lld loci, %lld reads: pack %.1f ms\n", reads.size(), (long long)nl,
-                (long long)total, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_p0).count());
+    const auto t_p1 = std::chrono::steady_clock::now();
     // candidate window of every locus: [first alignment that ends behind it ... first alignment that starts behind it)
     size_t w0 = 0, w1 = 0;
     for (int64_t l = 0; l < nl; ++l) {
@@ -1027,6 +1235,11 @@ int64_t smc_bam_alignments(void* h, const char* chrom, int64_t start0, int64_t e
         pl[l].slot_off = l_off[(size_t)l]; pl[l].n = l_n[(size_t)l];
     }
     *n_loci_done = nl; *n_slots = slots; *n_bc_out = n_bc; *n_pair_out = n_pair; *status = st;
+    if (getenv("SMC_BAM_TIMING")) {
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "smc_bam_alignments: %zu alignments, %lld loci, %lld reads: collect %.1f ms, depth + sizes %.1f ms, pack %.1f ms, windows %.1f ms\n",
+                reads.size(), (long long)nl, (long long)total, ms(t_a0, t_a1), ms(t_a1, t_p0), ms(t_p0, t_p1), ms(t_p1, std::chrono::steady_clock::now()));
+    }
     return total;
 }
 

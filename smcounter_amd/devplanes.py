@@ -20,6 +20,8 @@ from . import _lib, abi, bamio
 from .features import LF_SAMPLED, LOCUS_DTYPE, USTART_DROPPED
 from .pileup import BASE_ALLELES
 
+_BASE_TABLE = list(BASE_ALLELES)           # the allele table of a locus that met only the six fixed keys (shared: read-only)
+
 
 _TIMES = {"decode": 0.0, "upload+launch": 0.0, "kernel (sync)": 0.0}      # SMC_DEVPLANES_TIMING=1: seconds per stage
 
@@ -62,6 +64,15 @@ def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], par
     max_depth = L.smc_build_max_depth()
     cp = abi.c_params(params)
     i, n = 0, len(loci)
+    # last locus of the stretch of consecutive positions (same chromosome) every locus lies in
+    if n:
+        pos_all = np.array([p for _, p in loci]).astype(np.int64)
+        chrom_all = [c for c, _ in loci]
+        brk = pos_all[1:] != pos_all[:-1] + 1
+        if chrom_all.count(chrom_all[0]) != n:
+            brk |= np.array([chrom_all[k] != chrom_all[k + 1] for k in range(n - 1)], bool)
+        ends = np.append(np.flatnonzero(brk), n - 1)
+        stretch_end = ends[np.searchsorted(ends, np.arange(n))]
     cap = max_reads + (max_reads >> 3) + 65536
     per_locus = 0.0          # pileup reads per locus of the previous run: sizes the next run (a run is decoded as a whole)
     while i < n:
@@ -79,9 +90,8 @@ def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], par
             span_cap = 65536 if per_locus <= 0 else int(max(1024, min(65536, 1.15 * (max_reads - total) / per_locus)))
             if per_locus <= 0 and i == first:
                 span_cap = 8192
-            while j + 1 < n and loci[j + 1][0] == chrom and int(loci[j + 1][1]) == int(loci[j][1]) + 1 and j + 1 - i < span_cap:
-                j += 1
-            lo, hi = int(loci[i][1]) - 1, int(loci[j][1])
+            j = min(int(stretch_end[i]), i + span_cap - 1)
+            lo, hi = int(pos_all[i]) - 1, int(pos_all[j])
             run_ref = fasta.fetch(chrom, lo, hi).upper()
             umi_base = slots + n_loc
             done = None
@@ -111,14 +121,15 @@ def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], par
             n_loc += nl
             total += int(lc["n_reads"].sum())
             chroms += [chrom] * nl
-            poss += list(range(lo + 1, lo + 1 + nl))
-            refs += [run_ref[k:k + 1] for k in range(nl)]
+            poss.append(np.arange(lo + 1, lo + 1 + nl, dtype=np.int64))
+            refs += list(run_ref[:nl]) + [""] * max(0, nl - len(run_ref))
             tables += tb
             i += nl
         lc_all = LC[0] if len(LC) == 1 else np.concatenate(LC)
         uaux[1].free(); uaux[2].free()
         yield first, ResidentBatch(planes=planes + [uaux[0]], n_slots=slots, n_ustart=slots + n_loc + 1,
-                                   loci=lc_all, chrom=chroms, pos=np.array(poss, np.int64), ref=refs, alleles=tables,
+                                   loci=lc_all, chrom=chroms, pos=poss[0] if len(poss) == 1 else np.concatenate(poss) if poss else np.zeros(0, np.int64),
+                                   ref=refs, alleles=tables,
                                    n_device_runs=n_dev, n_host_runs=n_host)
     bam.close()
 
@@ -131,7 +142,7 @@ def _device_run(bam, L, eng, cp, params, chrom, lo, hi, max_reads, nthreads, fas
     from .engine import DevBuf
     T = _TIMES if os.environ.get("SMC_DEVPLANES_TIMING") else None
     t0 = time.perf_counter()
-    A = bam.alignments_run(chrom, lo, hi, max_reads, params, nthreads)
+    A = bam.alignments_run(chrom, lo, hi, max_reads, params, nthreads, host_array=eng.pinned)
     t1 = time.perf_counter()
     nl, ns = A["nl"], A["n_slots"]
     if nl == 0:
@@ -163,8 +174,10 @@ def _device_run(bam, L, eng, cp, params, chrom, lo, hi, max_reads, nthreads, fas
             raise PileupError("base quality > 126 at %s:%d-%d" % (chrom, lo + 1, lo + nl))
         return None
     lc = d_loci.download(LOCUS_DTYPE, nl)
+    for b in (d_aln, d_cig, d_seq, d_qual, d_loc, d_ref, d_loci, d_cnt):
+        b.free()                              # (back to the engine's spare list right away, not whenever the collector gets to them)
     # allele tables: the six fixed keys + what the kernel met, in the order it numbered them
-    tables = [list(BASE_ALLELES) for _ in range(nl)]
+    tables = [_BASE_TABLE] * nl                 # (shared, never written: a locus that met more alleles gets its own list)
     nx = int(cnt[0])
     if nx:
         xl = d_x.download(np.uint32, 5 * nx).reshape(nx, 5)
@@ -175,6 +188,8 @@ def _device_run(bam, L, eng, cp, params, chrom, lo, hi, max_reads, nthreads, fas
                 ln, site = key[1:].split("|")
                 pos1 = lo + l + 1
                 key = "DEL|" + site + fasta.fetch(chrom, pos1, pos1 + int(ln)).upper() + "|" + site
+            if tables[l] is _BASE_TABLE:
+                tables[l] = list(BASE_ALLELES)
             assert aid == len(tables[l]), (l, aid, len(tables[l]))
             tables[l].append(key)
     # the reference's down-sampling (smCounter.py:496-498) on loci over the barcode cap: barcode texts by first included read

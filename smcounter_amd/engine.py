@@ -20,9 +20,16 @@ class DevBuf(object):
     that a single-process run never imports PyTorch.  Quacks like one where the bindings need it (`data_ptr()`)."""
 
     def __init__(self, eng, nbytes: int):
+        # Sizes are rounded up to {1, 1.25, 1.5, 1.75} x 2^k and a freed allocation waits in the engine for the next request
+        # of its size class (a batch allocates and frees some twenty buffers; the runtime's free synchronises the device)
         self.eng, self.nbytes = eng, int(nbytes)
+        self.cls = _size_class(self.nbytes)
+        spare = eng._spare.get(self.cls)
+        if spare:
+            self.ptr = spare.pop()
+            return
         p = ctypes.c_void_p()
-        _lib.check(eng.L.smc_mem_alloc(eng.ctx, self.nbytes, ctypes.byref(p)), "smc_mem_alloc")
+        _lib.check(eng.L.smc_mem_alloc(eng.ctx, self.cls, ctypes.byref(p)), "smc_mem_alloc")
         self.ptr = p.value or 0
 
     def data_ptr(self) -> int:
@@ -34,8 +41,10 @@ class DevBuf(object):
         _lib.check(self.eng.L.smc_mem_h2d(self.eng.ctx, self.ptr + offset_bytes, arr.ctypes.data, arr.nbytes), "smc_mem_h2d")
         return self
 
-    def download(self, dtype, count: int, offset_bytes: int = 0) -> np.ndarray:
-        out = np.empty(count, dtype)
+    def download(self, dtype, count: int, offset_bytes: int = 0, out: np.ndarray = None) -> np.ndarray:
+        if out is None:
+            out = np.empty(count, dtype)
+        assert out.dtype == np.dtype(dtype) and len(out) == count and out.flags.c_contiguous
         assert offset_bytes + out.nbytes <= self.nbytes
         _lib.check(self.eng.L.smc_mem_d2h(self.eng.ctx, out.ctypes.data, self.ptr + offset_bytes, out.nbytes), "smc_mem_d2h")
         return out
@@ -46,7 +55,7 @@ class DevBuf(object):
 
     def free(self):
         if self.ptr and self.eng.ctx:
-            self.eng.L.smc_mem_free(self.eng.ctx, self.ptr)
+            self.eng._spare.setdefault(self.cls, []).append(self.ptr)
         self.ptr = 0
 
     def __del__(self):
@@ -54,6 +63,13 @@ class DevBuf(object):
             self.free()
         except Exception:
             pass
+
+
+def _size_class(n: int) -> int:
+    n = max(256, int(n))
+    k = n.bit_length() - 1                    # 2^k <= n
+    q = 1 << max(0, k - 2)                    # quarter steps
+    return (n + q - 1) // q * q
 
 
 class _DevView(object):
@@ -73,9 +89,39 @@ class Engine(object):
         h = ctypes.c_void_p()
         _lib.check(self.L.smc_create(device, ctypes.byref(h)), "smc_create")
         self.ctx = h
+        self._spare = {}                      # size class -> freed DevBuf pointers, reused before allocating anew
+        self._pinned = {}                     # name -> (pointer, bytes) of page-locked staging memory
+
+    def pinned(self, name: str, dtype, count: int) -> np.ndarray:
+        """A numpy array over page-locked host memory owned by the engine, one per `name`, grown when needed: staging for the
+        copies of a run (valid until the next request under the same name)."""
+        dtype = np.dtype(dtype)
+        need = max(1, int(count)) * dtype.itemsize
+        slot = self._pinned.get(name)
+        if slot is None or slot[1] < need:
+            if slot is not None:
+                self.L.smc_mem_free_host(self.ctx, slot[0])
+            size = _size_class(need + need // 4)
+            p = ctypes.c_void_p()
+            _lib.check(self.L.smc_mem_alloc_host(self.ctx, size, ctypes.byref(p)), "smc_mem_alloc_host")
+            slot = self._pinned[name] = (p.value, size)
+        raw = (ctypes.c_ubyte * need).from_address(slot[0])
+        return np.frombuffer(raw, dtype, int(count))
+
+    def trim(self):
+        """Give the cached device buffers (DevBuf) back to the runtime."""
+        if self.ctx:
+            for ptrs in self._spare.values():
+                for p in ptrs:
+                    self.L.smc_mem_free(self.ctx, p)
+        self._spare = {}
 
     def close(self):
         if self.ctx:
+            self.trim()
+            for p, _ in self._pinned.values():
+                self.L.smc_mem_free_host(self.ctx, p)
+            self._pinned = {}
             self.L.smc_destroy(self.ctx)
             self.ctx = None
 
@@ -139,10 +185,12 @@ class Plan(object):
         return rows
 
     def run_devbuf(self, planes, params: VcParams) -> np.ndarray:
-        """The torch-free path: planes are DevBuf / views, the rows come back as a numpy array (synchronous)."""
+        """The torch-free path: planes are DevBuf / views, the rows come back as a numpy array (synchronous) - over the engine's
+        page-locked staging memory: valid until the next run_devbuf on this engine."""
         rows = DevBuf(self.eng, self.n_loci * abi.ROW_DTYPE.itemsize)
         self.run(planes, params, rows, stream=0)
-        out = rows.download(abi.ROW_DTYPE, self.n_loci)     # (hipMemcpy on the default stream: ordered behind the kernels)
+        # (hipMemcpy on the default stream: ordered behind the kernels)
+        out = rows.download(abi.ROW_DTYPE, self.n_loci, out=self.eng.pinned("rows", abi.ROW_DTYPE, self.n_loci))
         rows.free()
         return out
 

@@ -56,32 +56,48 @@ def _apply_one(row: str, trf, rm) -> str:
     return "\t".join(f)
 
 
-def apply_repeat_filters(rows: List[str], trf, rm) -> List[str]:
+def apply_repeat_filters(rows: List[str], trf, rm, pred=None) -> List[str]:
     """Append RepT / RepS / LowC / SL / Other_Repeat to the raw FILTER of rows with int(PI) >= 5 and
     ALT != 'DEL', then turn ';' into PASS and strip the semicolons (smCounter.py:751-785).  Rows whose
     POS or VMF is not numeric (the Zero_Coverage rows) pass through untouched, as in the reference.
     (`_apply_one` is the plain statement; the loop below does the same on the unchanged rows - nearly all of a
-    panel: PI below 5, FILTER ';' - without splitting all 45 fields.)"""
+    panel: PI below 5, FILTER ';' - without splitting all 45 fields.)
+    `pred` (optional, rows.RowLines.pred): per row int(float(PI)) as the native printer saw it, for rows it printed with
+    numeric POS / VMF and the raw FILTER ';' (rows.PRED_NONE elsewhere): those below 5 - nearly all of a panel - become
+    '...PASS' by one replace over the joined text instead of a Python step per row."""
+    if pred is not None and len(pred) == len(rows) and rows:
+        import numpy as np
+        from .rows import PRED_NONE
+        pred = np.asarray(pred)
+        out = list(rows)
+        special = np.flatnonzero((pred >= 5) | (pred == PRED_NONE)).tolist()
+        for i in special:
+            out[i] = _apply_any(out[i], trf, rm)
+        text = "\n".join(out)
+        # (a treated row that keeps a bare ';' - POS / VMF not numeric: passed through untouched - or a line break inside a
+        # row: the plain way)
+        if text.count("\n") == len(out) - 1 and not any(out[i].endswith("\t;") for i in special):
+            return (text + "\n").replace("\t;\n", "\tPASS\n")[:-1].split("\n")
+        return [_apply_any(r, trf, rm) for r in rows]
     out = []
-    i_pi, i_vmf = _COL["PI"], _COL["VMF"]
-    assert i_pi < i_vmf and _COL["FILTER"] == len(HEADER_ALL) - 1
     for row in rows:
-        if not row.endswith("\t;"):
-            out.append(_apply_one(row, trf, rm))
-            continue
-        head = row.split("\t", i_vmf + 1)
-        if len(head) != i_vmf + 2:
-            out.append(_apply_one(row, trf, rm))
-            continue
-        try:
-            int(head[_COL["POS"]])
-            float(head[i_vmf])
-            pred = int(float(head[i_pi]))
-        except ValueError:
-            out.append(_apply_one(row, trf, rm))
-            continue
-        if pred >= 5:
-            out.append(_apply_one(row, trf, rm))
-        else:
-            out.append(row[:-1] + "PASS")
+        out.append(_apply_any(row, trf, rm))
     return out
+
+
+def _apply_any(row: str, trf, rm) -> str:
+    i_pi, i_vmf = _COL["PI"], _COL["VMF"]
+    if not row.endswith("\t;"):
+        return _apply_one(row, trf, rm)
+    head = row.split("\t", i_vmf + 1)
+    if len(head) != i_vmf + 2:
+        return _apply_one(row, trf, rm)
+    try:
+        int(head[_COL["POS"]])
+        float(head[i_vmf])
+        pred = int(float(head[i_pi]))
+    except ValueError:
+        return _apply_one(row, trf, rm)
+    if pred >= 5:
+        return _apply_one(row, trf, rm)
+    return row[:-1] + "PASS"

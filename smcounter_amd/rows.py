@@ -114,6 +114,11 @@ def _rowfmt():
         L.smc_rowfmt_stride.restype = C.c_int
         L.smc_format_tails.restype = C.c_int64
         L.smc_format_tails.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.smc_rowfmt_line_stride.restype = C.c_int
+        L.smc_rowfmt_line_stride.argtypes = [C.c_int]
+        L.smc_format_lines.restype = C.c_int64
+        L.smc_format_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         _ROWFMT = L
     return _ROWFMT
 
@@ -134,6 +139,50 @@ def format_tails(rows, chosen=None):
     return buf[:nb - 1].tobytes().decode("ascii").split("\n")
 
 
+class RowLines(list):
+    """The 45-field strings of a batch, plus what the native printer knows about them: `pred` - per row
+    int(float(PI column)), the number the repeat filters and the writers compare (smCounter.py:757, :838), or PRED_NONE
+    for a row it did not print - so that the stages behind vc() need not split every string to find it again."""
+    pred = None
+
+
+PRED_NONE = -(1 << 31)
+_SNP_LETTER = None
+
+
+def format_lines(rows, chosen, chrom, pos, ref, alt):
+    """Native printer, whole lines (smc_format_lines): rows with alt[i] != 0 come back as the complete string vc() returns for
+    a locus no filter applies to, the others as their 39 numeric columns ('' = left to the caller).  -> (lines, pred)"""
+    import ctypes as C
+    import numpy as np
+    n = len(rows)
+    L = _rowfmt()
+    rows = np.ascontiguousarray(rows)
+    assert rows.dtype.itemsize == 432
+    names, ids = [], {}
+    chrom_id = np.empty(n, np.int32)
+    if n and isinstance(chrom, list) and chrom.count(chrom[0]) == n:      # (one chromosome: the usual batch)
+        names = [chrom[0]]; chrom_id[:] = 0
+    else:
+        for i, c in enumerate(chrom):
+            k = ids.get(c)
+            if k is None:
+                k = ids[c] = len(names); names.append(c)
+            chrom_id[i] = k
+    enc = [c.encode() for c in names]
+    off = np.zeros(len(enc) + 1, np.int32)
+    off[1:] = np.cumsum([len(e) for e in enc])
+    mx = max((len(e) for e in enc), default=0)
+    buf = np.empty(n * L.smc_rowfmt_line_stride(mx), np.uint8)
+    pred = np.empty(n, np.int32)
+    ch = np.ascontiguousarray(chosen, np.int8)
+    posa = np.ascontiguousarray(pos, np.int64)
+    import os
+    nb = L.smc_format_lines(rows.ctypes.data, ch.ctypes.data, n, b"".join(enc), off.ctypes.data, chrom_id.ctypes.data, posa.ctypes.data,
+                            ref.ctypes.data, alt.ctypes.data, mx, min(16, len(os.sched_getaffinity(0))), buf.ctypes.data, pred.ctypes.data)
+    return buf[:nb - 1].tobytes().decode("ascii").split("\n"), pred
+
+
 def format_rows(rows, db, params: VcParams, refprov, native: bool = True):
     """`format_row` over a batch.  The numeric columns (39 of the 45) of every callable locus are printed by the
     native formatter in one call (`format_tails`); Python adds CHROM..TYPE and FILTER.  Loci whose candidate goes
@@ -151,34 +200,52 @@ def format_rows(rows, db, params: VcParams, refprov, native: bool = True):
     simple = callable_ & (rows["biallelic"] == 0) & (cand0["flt_applied"] == 0)
     if not native:
         return _format_rows_py(rows, db, params, refprov, simple.tolist())
-    out = [None] * n
     chosen = np.where(callable_, 0, -1).astype(np.int8)
     heads = {}
-    pos_s = [str(int(p)) for p in (db.pos.tolist() if hasattr(db.pos, "tolist") else db.pos)]
-    for l in np.flatnonzero(callable_ & ~simple).tolist():
-        ref, alt, vtype, fltr, ci = _head_and_filter(rows[l], db.chrom[l], pos_s[l], db.ref[l], db.alleles[l], params, refprov)
-        chosen[l] = ci
-        heads[l] = ("\t".join((db.chrom[l], pos_s[l], ref, alt, vtype)), fltr)
-    tails = format_tails(rows, chosen)
-    c_allele = cand0["allele"].tolist()
-    simple = simple.tolist()
     chrom, refs, alleles = db.chrom, db.ref, db.alleles
-    for l in range(n):
-        t = tails[l]
-        if not t:                                   # Zero_Coverage / bad input / out of the native printer's range
-            out[l] = format_row(rows[l], chrom[l], db.pos[l], refs[l], alleles[l], params, refprov)
-        elif simple[l]:
-            r = refs[l]
-            a = alleles[l][c_allele[l]]
-            if len(a) == 1:                         # convert_to_vcf, SNP case inlined
-                out[l] = chrom[l] + "\t" + pos_s[l] + "\t" + r + "\t" + a + "\tSNP\t" + t + "\t;"
+    for l in np.flatnonzero(callable_ & ~simple).tolist():
+        ps = str(int(db.pos[l]))
+        ref, alt, vtype, fltr, ci = _head_and_filter(rows[l], chrom[l], ps, refs[l], alleles[l], params, refprov)
+        chosen[l] = ci
+        heads[l] = ("\t".join((chrom[l], ps, ref, alt, vtype)), fltr)
+    # A simple locus whose candidate is one of A, T, G, C, N (allele ids 0-4, fixed) on a one-letter reference base is a
+    # "SNP" line (convert_to_vcf :103-117 with equal lengths) that needs no string work at all: printed whole.
+    c_allele = cand0["allele"]
+    ref_b = _ref_letters(refs, n)
+    alt_b = np.where(simple & (c_allele >= 0) & (c_allele <= 4) & (ref_b != 0),
+                     np.frombuffer(b"ATGCN\0\0\0", np.uint8)[np.clip(c_allele, 0, 5)], 0).astype(np.uint8)
+    lines, pred = format_lines(rows, chosen, chrom, db.pos, ref_b, alt_b)
+    out = RowLines(lines)
+    out.pred = pred
+    # what is left: rows the printer declined, simple loci with an indel / 'DEL' candidate, loci with filters
+    todo = np.flatnonzero((alt_b == 0) | (pred == PRED_NONE)).tolist()
+    if todo:
+        c_allele = c_allele.tolist()
+        simple = simple.tolist()
+        for l in todo:
+            t = lines[l]
+            if not t:                                   # Zero_Coverage / bad input / out of the native printer's range
+                out[l] = format_row(rows[l], chrom[l], db.pos[l], refs[l], alleles[l], params, refprov)
+            elif simple[l]:
+                ref, alt, vtype = convert_to_vcf(refs[l], alleles[l][c_allele[l]])
+                out[l] = "\t".join((chrom[l], str(int(db.pos[l])), ref, alt, vtype, t, ";"))
             else:
-                ref, alt, vtype = convert_to_vcf(r, a)
-                out[l] = "\t".join((chrom[l], pos_s[l], ref, alt, vtype, t, ";"))
-        else:
-            h, fltr = heads[l]
-            out[l] = h + "\t" + t + "\t" + fltr
+                h, fltr = heads[l]
+                out[l] = h + "\t" + t + "\t" + fltr
+                if fltr != ";":
+                    pred[l] = PRED_NONE                 # (the post-filter looks at this row itself)
     return out
+
+
+def _ref_letters(refs, n):
+    """The loci's reference bases as bytes (0 where it is not exactly one ASCII letter)."""
+    import numpy as np
+    if isinstance(refs, str) and len(refs) == n and refs.isascii():
+        return np.frombuffer(refs.encode(), np.uint8).copy()
+    s = "".join(refs)
+    if len(s) == n and s.isascii() and max(map(len, refs), default=1) == 1:
+        return np.frombuffer(s.encode(), np.uint8).copy()
+    return np.array([ord(r) if len(r) == 1 and ord(r) < 128 else 0 for r in refs], np.uint8)
 
 
 def _format_rows_py(rows, db, params: VcParams, refprov, simple):

@@ -30,6 +30,16 @@ def vc_batch(pb, params: VcParams, refprov, eng: Optional[_engine.Engine] = None
     finally:
         if own:
             eng.close()
+    return _strings(out_rows, db, params, refprov)
+
+
+def _strings(out_rows, db, params: VcParams, refprov) -> List[str]:
+    """The batch's rows as the strings vc() returns (smCounter.py:599): the batch formatter, or - when a locus fails in it -
+    locus by locus with the reference's failure convention (:605-611) for the one that does."""
+    try:
+        return rows.format_rows(out_rows, db, params, refprov)
+    except Exception:
+        pass
     text = []
     for l in range(db.n_loci):
         try:
@@ -49,18 +59,7 @@ def vc_resident(rb, params: VcParams, refprov, eng: _engine.Engine) -> List[str]
         out_rows = plan.run_devbuf(rb.planes, params)
     finally:
         plan.close()
-    text = []
-    try:
-        return rows.format_rows(out_rows, rb, params, refprov)
-    except Exception:
-        pass
-    for l in range(rb.n_loci):                       # (a failing locus: find it, the reference's failure convention)
-        try:
-            text.append(rows.format_row(out_rows[l], rb.chrom[l], rb.pos[l], rb.ref[l], rb.alleles[l], params, refprov))
-        except Exception:
-            print("Exception thrown in vc() function at genome location:", rb.chrom[l], int(rb.pos[l]))
-            text.append(EXC_PREFIX + "\n" + traceback.format_exc())
-    return text
+    return _strings(out_rows, rb, params, refprov)
 
 
 def raise_on_exception(output: List[str], loc_list) -> None:

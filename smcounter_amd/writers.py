@@ -60,8 +60,15 @@ def _genotype(chrom: str, alts: List[str], vmf: str) -> str:
     return "1/1" if float(vmf) > 0.95 else "0/1"
 
 
-def write_outputs(out_prefix: str, rows: List[str], threshold: int) -> None:
-    """rows: post-filtered 45-column strings in locus order."""
+def write_outputs(out_prefix: str, rows: List[str], threshold: int, pred=None) -> None:
+    """rows: post-filtered 45-column strings in locus order.  `pred` (optional, rows.RowLines.pred): per row int(float(PI)) where
+    the native printer knows it - rows below the threshold are then not split again to find that out."""
+    cut_rows = rows
+    if pred is not None and len(pred) == len(rows):
+        import numpy as np
+        from .rows import PRED_NONE
+        pred = np.asarray(pred)
+        cut_rows = [rows[i] for i in np.flatnonzero((pred >= threshold) | (pred == PRED_NONE)).tolist()]
     sample_col = "\t".join(("#CHROM", "POS", "ID", "REF", "ALT", "QUAL", "FILTER", "INFO", "FORMAT", out_prefix))
     with open(out_prefix + ".smCounter.all.txt", "w") as f_all, \
             open(out_prefix + ".smCounter.cut.txt", "w") as f_cut, \
@@ -72,7 +79,7 @@ def write_outputs(out_prefix: str, rows: List[str], threshold: int) -> None:
         if rows:
             f_all.write("\n".join(rows) + "\n")
         i_pi, i_alt = _COL["PI"], _COL["ALT"]
-        for row in rows:
+        for row in cut_rows:
             f = row.split("\t", i_pi + 1)                    # (most rows stop here: PI below the threshold)
             if not f[i_pi]:
                 continue                                     # Zero_Coverage rows

@@ -282,7 +282,7 @@ def test_downsampled_golden_fixtures_exercise_the_sample():
 
 def test_batch_row_formatter_equals_the_per_row_one():
     import oracle_lib
-    n = 0
+    n = n_known = 0
     for path in golden_files():
         pb, db, P, refp, expected = load_golden(path)
         R = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE)
@@ -292,7 +292,36 @@ def test_batch_row_formatter_equals_the_per_row_one():
         assert fast == slow
         assert py == slow
         n += len(R)
-    assert n > 600
+        # the printer's side band: int(float(PI column)) of the rows it vouches for (raw FILTER ';', numeric POS / VMF) ...
+        i_pi = rows.HEADER_ALL.index("PI")
+        assert isinstance(fast, rows.RowLines) and len(fast.pred) == len(fast)
+        known = 0
+        for l, line in enumerate(fast):
+            if fast.pred[l] != rows.PRED_NONE:
+                f = line.split("\t")
+                assert f[-1] == ";" and int(float(f[i_pi])) == fast.pred[l]
+                float(f[rows.HEADER_ALL.index("VMF")]); int(f[1])
+                known += 1
+        n_known += known
+        # ... lets the post-filter and the writers skip those rows without changing a byte of what they produce
+        from smcounter_amd import postfilter, writers
+        import tempfile, os
+        chrom = db.chrom[0]
+        trf = {chrom: [(int(db.pos[0]) - 1, int(db.pos[len(R) // 2]), "RepT;")]}
+        rm = {chrom: [(int(db.pos[len(R) // 3]), int(db.pos[-1]), "RepS;LowC;")]}
+        plain = postfilter.apply_repeat_filters(list(fast), trf, rm)
+        quick = postfilter.apply_repeat_filters(fast, trf, rm, pred=fast.pred)
+        assert quick == plain
+        d = tempfile.mkdtemp()
+        for thr in (1, 5, 14, 60):
+            writers.write_outputs(os.path.join(d, "a"), plain, thr)
+            writers.write_outputs(os.path.join(d, "b"), quick, thr, pred=fast.pred)
+            for ext in (".smCounter.all.txt", ".smCounter.cut.txt"):
+                assert open(os.path.join(d, "a" + ext)).read() == open(os.path.join(d, "b" + ext)).read()
+            va = [l for l in open(os.path.join(d, "a.smCounter.cut.vcf")) if not l.startswith("#")]
+            vb = [l for l in open(os.path.join(d, "b.smCounter.cut.vcf")) if not l.startswith("#")]
+            assert va == vb
+    assert n > 600 and n_known > 300
 
 
 def test_native_number_printer_equals_py2_rounding_and_str():
@@ -374,7 +403,7 @@ def test_host_libraries_export_every_symbol_of_the_host_header():
     bam, fmt = ctypes.CDLL(build.build_bam()), ctypes.CDLL(build.build_rowfmt())
     assert len(declared) >= 14
     for name in declared:
-        lib = fmt if name in ("smc_rowfmt_stride", "smc_format_tails") else bam
+        lib = fmt if name in ("smc_rowfmt_stride", "smc_format_tails", "smc_rowfmt_line_stride", "smc_format_lines") else bam
         assert getattr(lib, name) is not None, name
 
 
