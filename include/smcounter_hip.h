@@ -320,12 +320,15 @@ int smc_unpack_rows(const smc_wire_row* wire, int64_t n, smc_row* rows);
  * down-sampling, :496-498), loci[n_loci] (read_off4 / umi_off already batch-relative), and for every allele beyond the six
  * fixed ones five words in xlist (locus, allele id, alignment, query position, indel; smc_bam_allele_key turns them into the
  * key text).  counters[0] = entries appended to xlist, counters[1] = status bits (0 = fine; see csrc/k_build_planes.inc:
- * 1 depth mismatch / more than smc_build_max_depth() reads at a locus, 2 extras overflow, 4 base quality > 126, 8 more
+ * 1 depth mismatch (a locus's reads differ from loc[].n, or exceed in->max_depth / smc_build_max_depth()), 2 extras overflow, 4 base quality > 126, 8 more
  * than 64 alleles) - the caller falls back to smc_bam_planes for the run when it is not 0.  Asynchronous on `stream`. */
 typedef struct smc_build_in {
     const smc_dev_aln* aln; const uint32_t* cig; const uint8_t* seq; const uint8_t* qual;
     const smc_dev_locus* loc; const uint8_t* refseq;
     int32_t start0, n_loci, n_bc, n_pair;
+    int32_t max_depth;   /* reads at the run's deepest locus (the caller counted them for loc[].n): sizes the scratch of loci
+                          * beyond the on-chip sort (8192 reads); 0 = no locus is deeper than that */
+    int32_t reserved;
 } smc_build_in;
 int smc_build_max_depth(void);
 int smc_build_planes(smc_ctx* ctx, const smc_params* params, const smc_build_in* in, uint32_t slot_base, uint32_t umi_base,

@@ -147,7 +147,8 @@ def _device_run(bam, L, eng, cp, params, chrom, lo, hi, max_reads, nthreads, fas
     nl, ns = A["nl"], A["n_slots"]
     if nl == 0:
         return 0, 0, np.zeros(0, LOCUS_DTYPE), []
-    if A["status"] != 0 or (len(A["loc"]) and int(A["loc"]["n"].max()) > max_depth) or slot_base + ns > cap or \
+    deepest = int(A["loc"]["n"].max()) if len(A["loc"]) else 0
+    if A["status"] != 0 or deepest > max_depth or slot_base + ns > cap or \
             umi_base + ns + nl + 1 > cap + 8192:
         return None
     up = lambda a: DevBuf(eng, max(4, a.nbytes)).upload(a.view(np.uint8).reshape(-1) if a.nbytes else np.zeros(4, np.uint8))
@@ -158,7 +159,7 @@ def _device_run(bam, L, eng, cp, params, chrom, lo, hi, max_reads, nthreads, fas
     d_x = DevBuf(eng, 20 * xcap)
     d_cnt = DevBuf(eng, 8)
     bi = abi.SmcBuildIn(d_aln.data_ptr(), d_cig.data_ptr(), d_seq.data_ptr(), d_qual.data_ptr(), d_loc.data_ptr(), d_ref.data_ptr(),
-                        lo, nl, A["n_bc"], A["n_pair"])
+                        lo, nl, A["n_bc"], A["n_pair"], deepest, 0)
     _lib.check(L.smc_build_planes(eng.ctx, ctypes.byref(cp), ctypes.byref(bi), slot_base, umi_base, planes[0].data_ptr(),
                                   planes[1].data_ptr(), planes[2].data_ptr(), planes[3].data_ptr(), uaux[0].data_ptr(),
                                   uaux[1].data_ptr(), uaux[2].data_ptr(), d_loci.data_ptr(), d_x.data_ptr(), xcap,

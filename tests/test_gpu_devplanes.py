@@ -98,6 +98,56 @@ def test_runs_the_device_path_does_not_take_fall_back(engine0, tmp_path):
         assert rb.n_device_runs == 0 and rb.n_host_runs >= 1
 
 
+@pytest.mark.parametrize("depth", [9000, 40000])
+def test_loci_deeper_than_the_on_chip_sort(engine0, tmp_path, depth):
+    """Loci beyond 8192 reads (the reference's own example run has 58 k per locus) take k_build_planes' second
+    instantiation - sort keys in global scratch, 8192-key stretches sorted in LDS, the wider compare-exchange steps on the
+    global array: the same bytes as the host builder, for loci either side of the limit in ONE run (shallow flanks, a deep
+    core), indel alleles, soft clips, pairs, and barcodes of very different sizes."""
+    from smcounter_amd import devplanes
+    rng = np.random.default_rng(depth)
+    L = 400
+    ref = "".join(rng.choice(list("ACGT"), size=L))
+    fa_path = str(tmp_path / "deep.fa")
+    open(fa_path, "w").write(">chrD\n" + ref + "\n")
+    recs = []
+    n_bc = max(50, depth // 9)
+    for i in range(depth // 2):
+        bc = int(rng.integers(0, n_bc)) if i % 3 else int(rng.integers(0, 5))       # a few giant barcodes
+        start = 100 + int(rng.integers(0, 6)) if i % 50 else int(rng.integers(20, 200))   # a deep core, shallow flanks
+        for mate in (0, 1):
+            pos = start + (0 if mate == 0 else int(rng.integers(0, 8)))
+            kind = rng.random()
+            if kind < 0.01:
+                cigar = [(0, 20), (1, 2), (0, 38)]; qlen = 60
+            elif kind < 0.02:
+                cigar = [(0, 25), (2, 3), (0, 35)]; qlen = 60
+            elif kind < 0.05:
+                cigar = [(4, 5), (0, 55)]; qlen = 60
+            else:
+                cigar = [(0, 60)]; qlen = 60
+            seq = "".join(rng.choice(list("ACGT"), size=qlen)) if kind < 0.05 else ref[pos:pos + 60]
+            if rng.random() < 0.02:
+                seq = seq[:30] + "ACGT"[int(rng.integers(0, 4))] + seq[31:]
+            recs.append(dict(tid=0, pos=pos, qname="r%d:x:BC%04d:y" % (i, bc), flag=(0x41 if mate == 0 else 0x91),
+                             mapq=int(rng.choice([20, 60])), cigar=cigar, seq=seq,
+                             qual=rng.choice([12, 25, 30, 37], size=qlen).astype(np.uint8).tolist(), nm=int(rng.integers(0, 3))))
+    recs.sort(key=lambda r: r["pos"])
+    bam = str(tmp_path / "deep.bam")
+    bamio.write_bam(bam, [("chrD", L)], recs)
+    bamio.write_bai(bam)
+    fa = fasta.FastaFile(fa_path)
+    loci = [("chrD", str(p)) for p in range(60, 200)]
+    P = VcParams(mtDepth=100000, rpb=2.0, hpLen=8)
+    host = list(bamio.iter_device_batches_native(bam, fa, loci, P, max_reads=64_000_000))
+    dev = list(devplanes.iter_resident_batches(bam, fa, loci, P, engine0, max_reads=64_000_000))
+    assert len(host) == len(dev) == 1
+    (_, hb), (_, rb) = host[0], dev[0]
+    assert int(hb.loci["n_reads"].max()) > 8192 and int(hb.loci["n_reads"].min()) < 8192
+    assert rb.n_device_runs >= 1 and rb.n_host_runs == 0
+    _same_batch(rb, hb)
+
+
 def test_cli_device_and_host_planes_write_the_same_files(tmp_path, monkeypatch):
     import bam_fixture
     from smcounter_amd import cli
