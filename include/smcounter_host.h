@@ -27,6 +27,9 @@ void smc_bam_close(void* h);
 int smc_bam_n_refs(void* h);
 const char* smc_bam_ref_name(void* h, int i);
 int64_t smc_bam_ref_len(void* h, int i);
+/* compressed bytes of the file that hold [start0, end0) of `chrom` according to the linear index (16 kb granules; -1: not
+ * known) - a coarse volume estimate for sizing a first run */
+int64_t smc_bam_span_bytes(void* h, const char* chrom, int64_t start0, int64_t end0);
 const char* smc_bam_error(void* h);
 
 /* Pileup of positions start0 .. end0-1 of `chrom` (0-based), per-read attributes kept column-wise inside the handle;

@@ -564,6 +564,8 @@ def _native_lib():
         lib.smc_bam_allele_key.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_char_p, C.c_int]
         lib.smc_bam_barcode_name.argtypes = [C.c_void_p, C.c_int32]
         lib.smc_bam_barcode_name.restype = C.c_char_p
+        lib.smc_bam_span_bytes.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int64]
+        lib.smc_bam_span_bytes.restype = C.c_int64
         _NATIVE = lib
     return _NATIVE
 
@@ -657,6 +659,10 @@ class NativeBam(object):
             raise BamError(self._lib.smc_bam_error(self._h).decode())
         got.update(nl=done.value, n_slots=n_slots.value, n_bc=n_bc.value, n_pair=n_pair.value, status=status.value, reads=n)
         return got
+
+    def span_bytes(self, chrom: str, lo: int, hi: int) -> int:
+        """Compressed bytes holding [lo, hi) of `chrom` per the linear index (16 kb granules); -1 when not known."""
+        return int(self._lib.smc_bam_span_bytes(self._h, chrom.encode(), lo, hi))
 
     def allele_key(self, ai: int, qpos: int, indel: int) -> str:
         import ctypes as C

@@ -16,6 +16,7 @@
 
 #include "smcounter_hip.h"   // smc_locus: the descriptor smc_bam_planes fills
 
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <atomic>
@@ -789,6 +790,26 @@ inline int allele_of(const Aln& a, int qpos, bool isdel, int indel, std::vector<
     return 6 + (int)k;
 }
 
+// The large buffers of a closed handle (inflated records, compressed stretch, alignment arrays: tens to hundreds of
+// megabytes) are parked here for the next handle of the process instead of being unmapped: unmapping takes milliseconds
+// - on the closing thread, or, from a helper thread, through the address-space lock on every thread that allocates meanwhile.
+struct SpareBuffers {
+    std::mutex m;
+    ByteBuf rec, comp;
+    RawVec<Aln> reads, parsed;
+};
+static SpareBuffers& spare_buffers() { static SpareBuffers* s = new SpareBuffers; return *s; }
+template <class B> static void keep_larger(B& spare, B& mine) {
+    if (mine.cap > spare.cap) { std::swap(spare.p, mine.p); std::swap(spare.cap, mine.cap); spare.n = 0; mine.n = 0; }
+}
+
+static void take_spare(Bam& b) {
+    SpareBuffers& S = spare_buffers();
+    std::lock_guard<std::mutex> lk(S.m);
+    keep_larger(b.rec_data, S.rec); keep_larger(b.comp, S.comp);
+    keep_larger(b.d_reads, S.reads); keep_larger(b.parsed, S.parsed);
+}
+
 }  // namespace
 
 extern "C" {
@@ -838,6 +859,7 @@ int smc_bam_open(const char* path, void** out) {
         }
         fclose(f);
     }
+    take_spare(*b);
     *out = b;
     return 0;
 }
@@ -847,10 +869,35 @@ void smc_bam_close(void* h) {
     if (!b) return;
     if (b->fh) fclose(b->fh);
     b->fh = nullptr;
-    // a handle that has decoded runs holds their buffers (tens to hundreds of megabytes): unmapping them takes
-    // milliseconds, which nobody has to wait for
-    if (b->rec_data.cap > (8u << 20)) { try { std::thread([b] { delete b; }).detach(); return; } catch (...) {} }
+    {
+        SpareBuffers& S = spare_buffers();
+        std::lock_guard<std::mutex> lk(S.m);
+        keep_larger(S.rec, b->rec_data); keep_larger(S.comp, b->comp);
+        keep_larger(S.reads, b->d_reads); keep_larger(S.parsed, b->parsed);
+    }
     delete b;
+}
+
+// compressed bytes of the file between the first alignments of the 16 kb windows holding start0 and the one behind end0,
+// from the linear index; -1 = not known (no index, reference not found).  Coarse: what a caller sizes a first run with.
+int64_t smc_bam_span_bytes(void* h, const char* chrom, int64_t start0, int64_t end0) {
+    Bam& b = *(Bam*)h;
+    int tid = -1;
+    for (size_t i = 0; i < b.ref_names.size(); ++i) if (b.ref_names[i] == chrom) tid = (int)i;
+    if (tid < 0 || (size_t)tid >= b.lin.size() || b.lin[(size_t)tid].empty() || end0 <= start0) return -1;
+    const auto& iv = b.lin[(size_t)tid];
+    long w0 = (long)std::min<int64_t>(start0 >> 14, (int64_t)iv.size() - 1);
+    while (w0 >= 0 && iv[(size_t)w0] == 0) --w0;
+    if (w0 < 0) return -1;
+    uint64_t v1 = 0;
+    for (size_t w = (size_t)(end0 >> 14) + 1; w < iv.size(); ++w) if (iv[w]) { v1 = iv[w]; break; }
+    if (!v1) {                                         // the run reaches the last indexed window: up to the end of the file
+        struct stat stt;
+        if (fstat(fileno(b.fh), &stt) != 0) return -1;
+        v1 = (uint64_t)stt.st_size << 16;
+    }
+    const uint64_t c0 = iv[(size_t)w0] >> 16, c1 = v1 >> 16;
+    return c1 > c0 ? (int64_t)(c1 - c0) : 0;
 }
 
 int smc_bam_n_refs(void* h) { return (int)((Bam*)h)->ref_names.size(); }

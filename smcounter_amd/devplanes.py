@@ -20,6 +20,7 @@ from . import _lib, abi, bamio
 from .features import LF_SAMPLED, LOCUS_DTYPE, USTART_DROPPED
 from .pileup import BASE_ALLELES
 
+READS_PER_BYTE = 2.5                       # pileup reads per compressed byte assumed when sizing a batch's first run
 _BASE_TABLE = list(BASE_ALLELES)           # the allele table of a locus that met only the six fixed keys (shared: read-only)
 
 
@@ -89,7 +90,15 @@ def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], par
             # would be decoded again by the next one)
             span_cap = 65536 if per_locus <= 0 else int(max(1024, min(65536, 1.15 * (max_reads - total) / per_locus)))
             if per_locus <= 0 and i == first:
+                # nothing decoded yet: the linear index tells how many compressed bytes the stretch holds; at READS_PER_BYTE
+                # pileup reads per byte (on the dense side of what BAMs of 100-150 bp reads give) that sizes the first run -
+                # too long a guess only means that the run stops at max_reads and the rest is decoded again
                 span_cap = 8192
+                jj = min(int(stretch_end[i]), i + 65536 - 1)
+                nb = bam.span_bytes(chrom, int(pos_all[i]) - 1, int(pos_all[jj]))
+                if nb >= 0 and not os.environ.get("SMC_FIRST_RUN_8192"):     # (the switch: measurement)
+                    est = READS_PER_BYTE * nb
+                    span_cap = int(max(8192, min(65536, (jj - i + 1) * (0.9 * max_reads / est if est > 0.9 * max_reads else 1.0))))
             j = min(int(stretch_end[i]), i + span_cap - 1)
             lo, hi = int(pos_all[i]) - 1, int(pos_all[j])
             run_ref = fasta.fetch(chrom, lo, hi).upper()

@@ -372,6 +372,13 @@ def test_native_decoder_many_blocks_several_index_windows(tmp_path, nthreads):
         assert [f for f, _ in want] == [f for f, _ in got]
         for (_, a), (_, b) in zip(want, got):
             _assert_device_batches_equal(a, b)
+    # the linear index as a volume estimate (what sizes a batch's first run): the whole reference is about the whole file,
+    # a part of it a part, an unknown reference unknown
+    nb = bamio.NativeBam(bam)
+    whole, part = nb.span_bytes("chrW", 0, L), nb.span_bytes("chrW", 20000, 40000)
+    assert 0.8 * os.path.getsize(bam) < whole <= os.path.getsize(bam) and 0 < part < 0.6 * whole
+    assert nb.span_bytes("chrQ", 0, 100) == -1
+    nb.close()
 
 
 def test_locus_weights_follow_depth_and_balance_the_shards(tmp_path):
