@@ -39,7 +39,7 @@ const char SEQ_CODE[] = "=ACMGRSVTWYHKDBN";
 // more than that.  run(n, f) executes f(0) .. f(n - 1), the caller taking part; tasks are claimed one by one.
 class Pool {
     std::vector<std::thread>* th = new std::vector<std::thread>();   // (a pointer: dropped, not destroyed, in a forked child)
-    std::mutex m;
+    std::mutex m, run_m;
     std::condition_variable cv, cv_done;
     const std::function<void(int)>* job = nullptr;
     int n_tasks = 0, busy = 0, invited = 0;
@@ -80,6 +80,7 @@ public:
         if (n <= 0) return;
         par = std::min(par, n);
         if (par <= 1) { for (int i = 0; i < n; ++i) f(i); return; }
+        std::lock_guard<std::mutex> one_at_a_time(run_m);         // (two decoders on two threads take turns; tasks never call run)
         std::unique_lock<std::mutex> lk(m);
         if (owner != getpid()) { if (owner) th = new std::vector<std::thread>(); owner = getpid(); busy = 0; }
         while ((int)th->size() < par - 1 && th->size() < 255) { const int id = (int)th->size(); th->emplace_back([this, id] { worker(id); }); }

@@ -484,3 +484,32 @@ def test_deletion_followed_by_insertion_takes_the_indel_branch(tmp_path):
     db_nat = [db for _, db in bamio.iter_device_batches_native(bam, fa, loci, P)]
     assert len(db_nat) == 1
     _assert_device_batches_equal(db_py, db_nat[0])
+
+
+def test_two_decoders_on_two_threads_share_the_worker_pool(tmp_path):
+    """The native decoder's stages run on one process-wide worker pool (csrc/smc_bam.cpp): two handles driven from two
+    Python threads (the command line's prefetch thread is one such user) take turns at it and produce the same planes as
+    alone, every time."""
+    import threading
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    cases = [_random_bam(tmp_path / "a", 11, True), _random_bam(tmp_path / "b", 23, True)]
+    P = VcParams(mtDepth=100, rpb=3.0)
+
+    def planes(case):
+        bam, fa_path, loci = case
+        fa = fasta.FastaFile(fa_path)
+        return [db.meta.tobytes() + db.frag.tobytes() for _, db in
+                bamio.iter_device_batches_native(bam, fa, loci, P, max_reads=3000, nthreads=4)]
+    alone = [planes(c) for c in cases]
+    got = [[], []]
+
+    def run(k):
+        for _ in range(8):
+            got[k].append(planes(cases[k]))
+    th = [threading.Thread(target=run, args=(k,)) for k in (0, 1)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for k in (0, 1):
+        assert len(got[k]) == 8 and all(x == alone[k] for x in got[k])
