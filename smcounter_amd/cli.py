@@ -54,11 +54,37 @@ def build_parser() -> argparse.ArgumentParser:
     return p
 
 
-def call_shard(args, params: VcParams, loci, device: int):
+class _EarlyEngine(object):
+    """Engine(device) created in a helper thread (binding the library, bringing up the GPU runtime, the context and its
+    tables: ctypes calls, the interpreter lock is free meanwhile); get() joins and hands it over, or re-raises."""
+
+    def __init__(self, device: int):
+        import threading
+        self._eng = self._err = None
+
+        def work():
+            try:
+                from . import _lib
+                from .engine import Engine
+                _lib.load(with_torch=False)
+                self._eng = Engine(device)
+            except BaseException as e:
+                self._err = e
+        self._t = threading.Thread(target=work, daemon=True)
+        self._t.start()
+
+    def get(self):
+        self._t.join()
+        if self._err is not None:
+            raise self._err
+        return self._eng
+
+
+def call_shard(args, params: VcParams, loci, device: int, early=None):
     """The per-locus rows (strings, smCounter.py:599) of a run of loci: BAM decode -> device batches -> kernels."""
     from .engine import Engine
     ref = fasta.FastaFile(args.refGenome)
-    eng = Engine(device)
+    eng = early.get() if early is not None else Engine(device)
     output = _Rows()
     decoder = os.environ.get("SMC_BAM_DECODER", "native")
     # (one process per GPU: the ranks of a node share its cores for decoding)
@@ -76,6 +102,10 @@ def call_shard(args, params: VcParams, loci, device: int):
         # (a batch only lives in HBM here - 16 B per read - so it can be eight times the host-built default)
         batches = devplanes.iter_resident_batches(args.bamFile, ref, loci, params, eng, max_reads=8 * args.batchReads,
                                                   nthreads=nthreads)
+        # (a batch ahead in a helper thread: decoding and building batch i + 1 overlaps the kernels and the strings of batch i;
+        # the two threads use different staging buffers of the engine, device work is ordered by the default stream)
+        if not os.environ.get("SMC_NO_PREFETCH"):
+            batches = _prefetch(batches, depth=1)
         for first, rb in batches:
             output.add(vc.vc_resident(rb, params, ref, eng))
         eng.close()
@@ -163,6 +193,10 @@ def _main(args) -> int:
 
     params = VcParams(minBQ=args.minBQ, minMQ=args.minMQ, mtDepth=args.mtDepth, rpb=args.rpb, hpLen=args.hpLen,
                       mismatchThr=args.mismatchThr, mtDrop=args.mtDrop, maxMT=args.maxMT, primerDist=args.primerDist)
+    early = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and os.environ.get("SMC_BAM_DECODER", "native") != "python":
+        # a single process: the GPU runtime and the context come up (~ 0.1 s) in a helper thread while the target is expanded
+        early = _EarlyEngine(args.device)
     loc_list = bedops.expand_loci(args.bedTarget)
     # One process per GPU when launched through torch.distributed.run: rank r calls a contiguous range of the
     # ordered locus list (loci share nothing, smCounter.py:683-685) on GPU LOCAL_RANK, rank 0 gathers the rows
@@ -182,7 +216,7 @@ def _main(args) -> int:
     else:
         lo, hi = 0, len(loc_list)
     if world == 1:
-        output = call_shard(args, params, loc_list[lo:hi], args.device)
+        output = call_shard(args, params, loc_list[lo:hi], args.device, **({"early": early} if early is not None else {}))
         vc.raise_on_exception(output, loc_list[lo:hi])
     else:
         # A failing locus (or a decoder error) on one rank must not leave the others waiting in the collective

@@ -14,7 +14,7 @@ import oracle_lib
 
 @pytest.fixture
 def cpu_cli(monkeypatch):
-    def cpu_call_shard(args, params, loci, device):
+    def cpu_call_shard(args, params, loci, device, early=None):
         ref = fasta.FastaFile(args.refGenome)
         out = []
         for _, db in bamio.iter_device_batches_native(args.bamFile, ref, loci, params, max_reads=args.batchReads):

@@ -135,7 +135,7 @@ def _cli_worker(rank, world, port, tmp, q):
     from smcounter_amd import abi, bamio, cli, fasta, rows
     import oracle_lib
 
-    def cpu_call_shard(args, params, loci, device):
+    def cpu_call_shard(args, params, loci, device, early=None):
         ref = fasta.FastaFile(args.refGenome)
         out = []
         for _, db in bamio.iter_device_batches_native(args.bamFile, ref, loci, params, max_reads=args.batchReads):
