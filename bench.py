@@ -259,7 +259,7 @@ def main():
                        "value_from": "median block", "spread_pct": round(100.0 * (max(blocks) - min(blocks)) / elapsed, 2)},
             "roofline": roofline_block(res.loci, k_ms, k_n, k_loci, k_reads, "%s:%d" % (a.config, n_loc)),
             "host_buffers": "inputs resident in HBM when the timed region starts; handing host buffers instead "
-                            "(smc_call_batch_host: H2D of 8 B/read + kernels + D2H of the rows) measured 1.92 M loci/s on C3 "
+                            "(smc_call_batch_host: H2D of 8 B/read + kernels + D2H of the rows) measured 1.94 M loci/s on C3 "
                             "(DESIGN.md section 5) - PCIe-bound, never `value`",
         }
         if cpu is not None:
