@@ -498,10 +498,18 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, RawVe
         const auto tc0 = std::chrono::steady_clock::now();
         BlockStream bs(b, voff, b.io_threads, stop_hint);
         std::vector<std::pair<size_t, size_t>> recs;    // (offset of the body in bs.data, size)
+        recs.reserve(bs.data.size() / 160 + 16);
         for (;;) {
             size_t rn;
             const uint8_t* rp = bs.next_record(rn);
             if (!rp) break;
+            // the walk is a chain of dependent loads, one cache line per record; records of a run are of similar size, so the
+            // headers of the next few are (mostly) where this one's size says - asked for ahead of the chain
+            {
+                const uint8_t* const lim = bs.data.data() + bs.data.size();
+                const size_t step = rn + 4;
+                for (int k = 3; k <= 6; ++k) { const uint8_t* q = rp - 4 + (size_t)k * step; if (q + 64 < lim) { __builtin_prefetch(q); __builtin_prefetch(q + 64); } }
+            }
             int32_t rt, rpos;
             memcpy(&rt, rp, 4); memcpy(&rpos, rp + 4, 4);
             if (rt < 0 || rt > tid || (rt == tid && rpos >= end0)) break;
