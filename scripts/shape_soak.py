@@ -28,6 +28,12 @@ for seed in range(first, first + n):
     got = eng.call_batch_host(db, P)
     want, fragile, pi_all = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE, return_fragile=True, return_pi_all=True)
     bad = abi.compare_rows(got, want, 1e-6, 1e-6, fragile, pi_all)
+    # the general path's shortcut for barcodes with many reference fragments against the full walk: integer columns equal, PI
+    # far inside the tolerance (a few 1e-12 per barcode: 1e-8 holds for thousands of barcodes)
+    os.environ["SMC_NO_LITE"] = "1"
+    full = eng.call_batch_host(db, P)
+    del os.environ["SMC_NO_LITE"]
+    bad += ["lite vs full walk: " + x for x in abi.compare_rows(got, full, 1e-8, 1e-12, fragile, pi_all)]
     if bad:
         bad_total += 1
         print("seed", seed, "shape", n_umi, "x", rpb, "loci", n_loci, "MISMATCH", bad[:3], flush=True)
