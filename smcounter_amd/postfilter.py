@@ -77,12 +77,40 @@ def apply_repeat_filters(rows: List[str], trf, rm, pred=None) -> List[str]:
         # (a treated row that keeps a bare ';' - POS / VMF not numeric: passed through untouched - or a line break inside a
         # row: the plain way)
         if text.count("\n") == len(out) - 1 and not any(out[i].endswith("\t;") for i in special):
-            return (text + "\n").replace("\t;\n", "\tPASS\n")[:-1].split("\n")
+            return _PassRows(out, (text + "\n").replace("\t;\n", "\tPASS\n"))
         return [_apply_any(r, trf, rm) for r in rows]
     out = []
     for row in rows:
         out.append(_apply_any(row, trf, rm))
     return out
+
+
+class _PassRows(object):
+    """The post-filtered rows as a sequence that already holds its own joined text: `rows` are final except that the
+    untouched ones (nearly all) still end in the raw ';' - an item is completed to 'PASS' when it is asked for - and `text`
+    is all of them, completed, newline-terminated: what the writer of all.txt wants, without a split and a second join."""
+
+    def __init__(self, rows, text):
+        self._rows, self.text = rows, text
+
+    def __len__(self):
+        return len(self._rows)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self._rows)))]
+        r = self._rows[i]
+        return r[:-1] + "PASS" if r.endswith("\t;") else r
+
+    def __iter__(self):
+        for r in self._rows:
+            yield r[:-1] + "PASS" if r.endswith("\t;") else r
+
+    def __eq__(self, other):
+        return list(self) == list(other)
+
+    def __ne__(self, other):
+        return not self == other
 
 
 def _apply_any(row: str, trf, rm) -> str:

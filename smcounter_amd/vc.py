@@ -64,6 +64,16 @@ def vc_resident(rb, params: VcParams, refprov, eng: _engine.Engine) -> List[str]
 
 def raise_on_exception(output: List[str], loc_list) -> None:
     """main()'s scan for worker failures (smCounter.py:689-694)."""
+    pred = getattr(output, "pred", None)
+    if pred is not None and len(pred) == len(output):
+        # (a row the native printer produced is no failure message: only the others are looked at)
+        import numpy as np
+        from .rows import PRED_NONE
+        for i in np.flatnonzero(np.asarray(pred) == PRED_NONE).tolist():
+            if output[i].startswith(EXC_PREFIX):
+                print(output[i])
+                raise Exception("Exception thrown in vc() at location: " + str(loc_list[i]))
+        return
     for line, loc in zip(output, loc_list):
         if line.startswith(EXC_PREFIX):
             print(line)

@@ -76,8 +76,8 @@ def write_outputs(out_prefix: str, rows: List[str], threshold: int, pred=None) -
         f_all.write("\t".join(HEADER_ALL) + "\n")
         f_cut.write("\t".join(HEADER_VARIANTS) + "\n")
         f_vcf.write("\n".join(_VCF_META) + "\n" + sample_col + "\n")
-        if rows:
-            f_all.write("\n".join(rows) + "\n")
+        if len(rows):
+            f_all.write(getattr(rows, "text", None) or "\n".join(rows) + "\n")     # (postfilter._PassRows brings its text)
         i_pi, i_alt = _COL["PI"], _COL["ALT"]
         for row in cut_rows:
             f = row.split("\t", i_pi + 1)                    # (most rows stop here: PI below the threshold)
