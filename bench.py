@@ -166,12 +166,20 @@ def main():
     import torch.distributed as dist
     from smcounter_amd import engine
     from smcounter_amd import dist as smcdist
+    # (SMC_BENCH_SHARE_GPU=1: every rank on GPU 0 with the gloo backend - a FUNCTIONAL check of the N > 1 path on a box with
+    # one GPU, where RCCL refuses two ranks on a device; its numbers are not a measurement of anything)
+    share_gpu = bool(os.environ.get("SMC_BENCH_SHARE_GPU"))
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     # (SMC_BENCH_FORCE_DIST=1 under a 1-process torch.distributed.run exercises the collective path on one GPU)
     use_dist = world > 1 or bool(os.environ.get("SMC_BENCH_FORCE_DIST"))
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     cfg = synth.CONFIGS[a.config]
     params = synth.params_for(cfg)
@@ -232,7 +240,7 @@ def main():
             dist.barrier()
         elapsed = time.perf_counter() - t_start
         if use_dist:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         blocks.append(elapsed)
@@ -254,7 +262,8 @@ def main():
                        "parallelism": "loci sharded x%d, %s" % (world, ("%s rows gathered to rank 0" % ("packed wire" if packed else "full"))
                                                                  if gather else ("single GPU" if world == 1 else
                                                                                  "rows left in each rank's HBM (--rows resident)")),
-                       "build_s": round(t_build, 1)},
+                       "build_s": round(t_build, 1), **({"note": "SMC_BENCH_SHARE_GPU: all ranks on one GPU through gloo - a functional "
+                                                                         "check of the N > 1 path, not a measurement"} if share_gpu else {})},
             "blocks": {"n": len(blocks), "steps_each": a.steps, "ms_per_step": [round(b / a.steps * 1e3, 4) for b in blocks],
                        "value_from": "median block", "spread_pct": round(100.0 * (max(blocks) - min(blocks)) / elapsed, 2)},
             "roofline": roofline_block(res.loci, k_ms, k_n, k_loci, k_reads, "%s:%d" % (a.config, n_loc)),

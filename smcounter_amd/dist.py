@@ -117,10 +117,12 @@ class RowPipeline(object):
         self.pending = [None] * len(self.bufs)
         self.n = 0
         self.recv = None
+        self.host_staged, self.recv_host = False, None
         if collective:
             import torch
             import torch.distributed as dist
             self.rank, self.world = dist.get_rank(), dist.get_world_size()
+            self.host_staged = dist.get_backend() == "gloo" and self.bufs[0].is_cuda
             if self.rank == dst:
                 self.recv = [[torch.empty_like(b) for _ in range(self.world)] for b in self.bufs]
 
@@ -132,6 +134,18 @@ class RowPipeline(object):
         produce(self.bufs[b])
         if self.collective:
             import torch.distributed as dist
+            if self.host_staged:
+                # (gloo: the collective runs on host copies - a functional path for boxes where RCCL cannot be used, e.g. two
+                # ranks sharing one GPU; not a performance path)
+                h = self.bufs[b].cpu()
+                if self.rank == self.dst and self.recv_host is None:
+                    import torch
+                    self.recv_host = [torch.empty_like(h) for _ in range(self.world)]
+                dist.gather(h, self.recv_host if self.rank == self.dst else None, dst=self.dst)
+                if self.rank == self.dst:
+                    for r, t in enumerate(self.recv_host):
+                        self.recv[b][r].copy_(t)
+                return b
             self.pending[b] = dist.gather(self.bufs[b], self.recv[b] if self.rank == self.dst else None, dst=self.dst,
                                           async_op=True)
         return b
