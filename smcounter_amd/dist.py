@@ -94,6 +94,9 @@ def init_from_env():
     import torch.distributed as dist
     rank, local_rank = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
     backend = os.environ.get("SMC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if os.environ.get("SMC_SHARE_GPU"):
+        # every rank on GPU 0, gloo between them: a functional run of the multi-rank path on a box with one GPU
+        local_rank, backend = 0, "gloo"
     if not dist.is_initialized():
         if backend == "nccl":
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
