@@ -148,6 +148,34 @@ def test_loci_deeper_than_the_on_chip_sort(engine0, tmp_path, depth):
     _same_batch(rb, hb)
 
 
+def test_targets_out_of_order_and_scattered(engine0, tmp_path):
+    """Targets visited out of coordinate order, single scattered positions among them (every stretch of consecutive positions
+    is a run of its own; the decoder's cursor has to go back): same batches as the host builder."""
+    import test_bamio
+    from smcounter_amd import devplanes
+    bam, fa_path, loci = test_bamio._random_bam(tmp_path, 31, True)
+    fa = fasta.FastaFile(fa_path)
+    blocks, cur = [], [loci[0]]
+    for a, b in zip(loci, loci[1:]):
+        if b[0] == a[0] and int(b[1]) == int(a[1]) + 1 and len(cur) < 17:
+            cur.append(b)
+        else:
+            blocks.append(cur); cur = [b]
+    blocks.append(cur)
+    rng = np.random.default_rng(5)
+    order = rng.permutation(len(blocks))
+    shuffled = [x for k in order for x in blocks[int(k)]]
+    shuffled = shuffled[::1][:len(shuffled) - 3] + shuffled[-1:] + shuffled[-3:-1]      # a scattered tail
+    assert shuffled != loci and len(shuffled) == len(loci)
+    P = VcParams(mtDepth=50, rpb=3.0, hpLen=8)
+    host = list(bamio.iter_device_batches_native(bam, fa, shuffled, P, max_reads=4000, nthreads=2))
+    dev = list(devplanes.iter_resident_batches(bam, fa, shuffled, P, engine0, max_reads=4000, nthreads=2))
+    assert len(host) == len(dev) > 1
+    for (f1, hb), (f2, rb) in zip(host, dev):
+        assert f1 == f2
+        _same_batch(rb, hb)
+
+
 def test_cli_device_and_host_planes_write_the_same_files(tmp_path, monkeypatch):
     import bam_fixture
     from smcounter_amd import cli
