@@ -530,3 +530,33 @@ def test_py2_emulation_against_the_independent_c_restatement():
             branch["pool" if n <= setsize else "reject"] += 1
         n_sets += 1
     assert n_sets == 10000 and branch["pool"] > 1000 and branch["reject"] > 1000, branch
+
+
+def test_native_lines_with_several_chromosomes_and_the_pass_rows_sequence():
+    """smc_format_lines with rows of several chromosomes in one call (names by id), and postfilter._PassRows - what
+    apply_repeat_filters returns on its fast path - as a sequence: items, slices, iteration, equality, its text."""
+    import oracle_lib
+    from smcounter_amd import postfilter
+    pb, db, P, refp, expected = load_golden(golden_files()[0])
+    R = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE)
+    n = len(R)
+    chrom2 = [("chrA" if l % 3 else "chr_other_%d" % (l % 2)) for l in range(n)]
+    db2 = dataclasses.replace(db, chrom=chrom2)
+    real = {c2: c for c2, c in zip(chrom2, db.chrom)}
+
+    class Renamed(object):                       # the same sequences under the new names
+        def get_reference_length(self, chrom):
+            return refp.get_reference_length(real[chrom])
+
+        def fetch(self, chrom, start, end):
+            return refp.fetch(real[chrom], start, end)
+    refp2 = Renamed()
+    fast = rows.format_rows(R, db2, P, refp2)
+    slow = [rows.format_row(R[l], chrom2[l], db.pos[l], db.ref[l], db.alleles[l], P, refp2) for l in range(n)]
+    assert list(fast) == slow
+    plain = postfilter.apply_repeat_filters(list(fast), {}, {})
+    quick = postfilter.apply_repeat_filters(fast, {}, {}, pred=fast.pred)
+    assert isinstance(quick, postfilter._PassRows) and len(quick) == n
+    assert quick == plain and plain == quick and not (quick != plain)
+    assert [quick[i] for i in range(n)] == plain and quick[2:7] == plain[2:7] and quick[-1] == plain[-1]
+    assert quick.text == "\n".join(plain) + "\n"
