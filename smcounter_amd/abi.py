@@ -164,8 +164,18 @@ def compare_rows(a: np.ndarray, b: np.ndarray, pi_tol=1e-6, p_tol=1e-6, fragile=
     order_dep = ("max_allele", "second_allele", "biallelic")
     mt_dep = ("umt", "vsm", "max_allele", "second_allele", "biallelic")
     fr = np.zeros(len(a), np.int64) if fragile is None else np.asarray(fragile, np.int64)
+    # The tallies that only filterVariants reads (SMC_T_FWD .. SMC_T_R2PRLE, words 1-8) are part of a row where a candidate
+    # goes through the filters (flt_applied); elsewhere a producer may leave them out (the GPU path does, the CPU restatement
+    # fills them always).  alleleCnt and the pair counts (words 0, 9, 10) are compared everywhere.
+    filt_words = np.zeros(a["ref_tal"].shape[1], bool)
+    filt_words[1:9] = True
+    applied = (a["cand"]["flt_applied"] != 0) & (b["cand"]["flt_applied"] != 0)            # [n, 2]
+    any_applied = applied.any(axis=1)
     for f in INT_FIELDS:
-        ne = (a[f] != b[f]).reshape(len(a), -1).any(axis=1)
+        if f == "ref_tal":
+            ne = ((a[f] != b[f]) & (~filt_words[None, :] | any_applied[:, None])).any(axis=1)
+        else:
+            ne = (a[f] != b[f]).reshape(len(a), -1).any(axis=1)
         if f in order_dep:
             ne &= keep
         if f in ("umt", "vsm"):
@@ -182,7 +192,10 @@ def compare_rows(a: np.ndarray, b: np.ndarray, pi_tol=1e-6, p_tol=1e-6, fragile=
         bad.append("pi max-abs-diff %g > %g" % (d.max(), pi_tol))
     keep &= firm
     for f in CAND_INT_FIELDS:
-        ne = (a["cand"][f] != b["cand"][f]).reshape(len(a), -1).any(axis=1) & keep
+        if f == "tal":
+            ne = ((a["cand"][f] != b["cand"][f]) & (~filt_words[None, None, :] | applied[:, :, None])).reshape(len(a), -1).any(axis=1) & keep
+        else:
+            ne = (a["cand"][f] != b["cand"][f]).reshape(len(a), -1).any(axis=1) & keep
         for i in np.nonzero(ne)[0][:5]:
             bad.append("locus %d: cand.%s %r != %r" % (i, f, a["cand"][f][i].tolist(),
                                                         b["cand"][f][i].tolist()))
