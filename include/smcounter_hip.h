@@ -191,7 +191,9 @@ typedef struct smc_cand {
     int32_t vmt;         /* MTCnt[allele] */
     int32_t vsm;         /* strongMTCnt[allele] */
     int32_t pad;
-    int32_t tal[SMC_NT]; /* tallies of this allele */
+    int32_t tal[SMC_NT]; /* tallies of this allele: alleleCnt and the pair counts (SMC_T_CNT, _CONCORD, _DISCORD) always; the eight
+                          * that only filterVariants reads (SMC_T_FWD .. SMC_T_R2PRLE) where flt_applied - the device does not
+                          * count them for a locus no candidate of which reaches the filters */
     double pi;           /* finalDict[allele], unrounded */
     double p_sb, p_r1, p_r2, p_pr; /* Fisher two-sided p-values of the four tests, NaN if not run */
 } smc_cand;
@@ -207,7 +209,7 @@ typedef struct smc_row {
     int32_t dp[4], umt[4], vsm[4]; /* A,T,G,C: alleleCnt, MTCnt, strongMTCnt */
     double pi[4];        /* A,T,G,C: finalDict, unrounded */
     uint64_t touched_mask;
-    int32_t ref_tal[SMC_NT];
+    int32_t ref_tal[SMC_NT]; /* tallies of the reference allele: as smc_cand.tal - the filter-only eight where a candidate has flt_applied */
     smc_cand cand[2];    /* [0] origAlt (:541), [1] secondMaxBase when biallelic */
 } smc_row;
 
