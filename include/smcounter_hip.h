@@ -209,7 +209,8 @@ typedef struct smc_row {
     int32_t dp[4], umt[4], vsm[4]; /* A,T,G,C: alleleCnt, MTCnt, strongMTCnt */
     double pi[4];        /* A,T,G,C: finalDict, unrounded */
     uint64_t touched_mask;
-    int32_t ref_tal[SMC_NT]; /* tallies of the reference allele: as smc_cand.tal - the filter-only eight where a candidate has flt_applied */
+    int32_t ref_tal[SMC_NT]; /* tallies of the reference allele: alleleCnt always, the filter-only eight where a candidate has
+                              * flt_applied; its pair counts are not kept (nothing reads them: the DP filter looks at the candidate's) */
     smc_cand cand[2];    /* [0] origAlt (:541), [1] secondMaxBase when biallelic */
 } smc_row;
 

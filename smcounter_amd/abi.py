@@ -166,14 +166,18 @@ def compare_rows(a: np.ndarray, b: np.ndarray, pi_tol=1e-6, p_tol=1e-6, fragile=
     fr = np.zeros(len(a), np.int64) if fragile is None else np.asarray(fragile, np.int64)
     # The tallies that only filterVariants reads (SMC_T_FWD .. SMC_T_R2PRLE, words 1-8) are part of a row where a candidate
     # goes through the filters (flt_applied); elsewhere a producer may leave them out (the GPU path does, the CPU restatement
-    # fills them always).  alleleCnt and the pair counts (words 0, 9, 10) are compared everywhere.
+    # fills them always).  alleleCnt is compared everywhere; the pair counts (words 9, 10: concordPairCnt / discordPairCnt)
+    # everywhere for the candidates - the DP filter reads the candidate's (:207) - and nowhere for the reference allele,
+    # whose pair counts nothing ever reads.
     filt_words = np.zeros(a["ref_tal"].shape[1], bool)
     filt_words[1:9] = True
+    ref_dead = np.zeros(a["ref_tal"].shape[1], bool)
+    ref_dead[9:11] = True
     applied = (a["cand"]["flt_applied"] != 0) & (b["cand"]["flt_applied"] != 0)            # [n, 2]
     any_applied = applied.any(axis=1)
     for f in INT_FIELDS:
         if f == "ref_tal":
-            ne = ((a[f] != b[f]) & (~filt_words[None, :] | any_applied[:, None])).any(axis=1)
+            ne = ((a[f] != b[f]) & ~ref_dead[None, :] & (~filt_words[None, :] | any_applied[:, None])).any(axis=1)
         else:
             ne = (a[f] != b[f]).reshape(len(a), -1).any(axis=1)
         if f in order_dep:
