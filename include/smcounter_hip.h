@@ -317,7 +317,7 @@ int smc_unpack_rows(const smc_wire_row* wire, int64_t n, smc_row* rows);
  * end distances and read class (smCounter.py:316-366, :371-452), barcode / fragment ids by first appearance (:462-471),
  * the barcode-major order, umi_start and the descriptor - byte for byte what smc_bam_planes builds on the host.
  * Everything in `in` and every output is a DEVICE pointer.  Outputs: the four planes (the run's slots start at
- * slot_base), umi_start / u_gid / u_finc (sized slots + loci of the batch; locus l of the run uses
+ * slot_base; `umi` and `dist` - the raw fields the locus kernels do not read - may be NULL: not written then), umi_start / u_gid / u_finc (sized slots + loci of the batch; locus l of the run uses
  * [umi_base + slot_off(l) + l, ... + n_umi(l)]; u_gid / u_finc - run-wide barcode id and first INCLUDED pileup index per
  * barcode - are filled only for loci with more barcodes than params->ds: what the host needs for the reference's
  * down-sampling, :496-498), loci[n_loci] (read_off4 / umi_off already batch-relative), and for every allele beyond the six

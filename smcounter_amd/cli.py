@@ -101,7 +101,7 @@ def call_shard(args, params: VcParams, loci, device: int, early=None):
         from . import devplanes
         # (a batch only lives in HBM here - 16 B per read - so it can be eight times the host-built default)
         batches = devplanes.iter_resident_batches(args.bamFile, ref, loci, params, eng, max_reads=8 * args.batchReads,
-                                                  nthreads=nthreads)
+                                                  nthreads=nthreads, all_planes=False)
         # (a batch ahead in a helper thread: decoding and building batch i + 1 overlaps the kernels and the strings of batch i;
         # the two threads use different staging buffers of the engine, device work is ordered by the default stream)
         if not os.environ.get("SMC_NO_PREFETCH"):

@@ -56,8 +56,10 @@ class ResidentBatch:
 
 
 def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], params, eng, max_reads: int = 32_000_000,
-                          nthreads: int = 0, force_host: bool = False):
-    """BAM -> `ResidentBatch` chunks: same loci per chunk as bamio.iter_device_batches_native, planes built on the GPU."""
+                          nthreads: int = 0, force_host: bool = False, all_planes: bool = True):
+    """BAM -> `ResidentBatch` chunks: same loci per chunk as bamio.iter_device_batches_native, planes built on the GPU.
+    `all_planes=False`: only the planes the locus kernels read (meta, frag) and umi_start are built and kept - half the
+    device memory of a batch; the `umi` and `dist` planes (raw fields, for checks) are then absent (None)."""
     from .engine import DevBuf
     L = eng.L
     bam = bamio.NativeBam(path)
@@ -78,7 +80,7 @@ def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], par
     per_locus = 0.0          # pileup reads per locus of the previous run: sizes the next run (a run is decoded as a whole)
     while i < n:
         first = i
-        planes = [DevBuf(eng, 4 * cap) for _ in range(4)]
+        planes = [DevBuf(eng, 4 * cap) if (all_planes or k in (0, 2)) else None for k in range(4)]
         uaux = [DevBuf(eng, 4 * (cap + 8192)) for _ in range(3)]      # umi_start, u_gid, u_finc
         LC, chroms, poss, refs, tables = [], [], [], [], []
         total = slots = n_loc = 0
@@ -114,7 +116,8 @@ def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], par
                 if slots + ns > cap or umi_base + len(ustart) > cap + 8192:
                     raise bamio.BamError("run of %d read slots does not fit the device arena" % ns)
                 for k in range(4):
-                    planes[k].upload(hp[k], 4 * slots)
+                    if planes[k] is not None:
+                        planes[k].upload(hp[k], 4 * slots)
                 uaux[0].upload(ustart, 4 * umi_base)
                 lc = lc.copy()
                 lc["read_off4"] += slots // 4
@@ -170,7 +173,8 @@ def _device_run(bam, L, eng, cp, params, chrom, lo, hi, max_reads, nthreads, fas
     bi = abi.SmcBuildIn(d_aln.data_ptr(), d_cig.data_ptr(), d_seq.data_ptr(), d_qual.data_ptr(), d_loc.data_ptr(), d_ref.data_ptr(),
                         lo, nl, A["n_bc"], A["n_pair"], deepest, 0)
     _lib.check(L.smc_build_planes(eng.ctx, ctypes.byref(cp), ctypes.byref(bi), slot_base, umi_base, planes[0].data_ptr(),
-                                  planes[1].data_ptr(), planes[2].data_ptr(), planes[3].data_ptr(), uaux[0].data_ptr(),
+                                  planes[1].data_ptr() if planes[1] is not None else None, planes[2].data_ptr(),
+                                  planes[3].data_ptr() if planes[3] is not None else None, uaux[0].data_ptr(),
                                   uaux[1].data_ptr(), uaux[2].data_ptr(), d_loci.data_ptr(), d_x.data_ptr(), xcap,
                                   d_cnt.data_ptr(), ctypes.c_void_p(0)), "smc_build_planes")
     t2 = time.perf_counter()

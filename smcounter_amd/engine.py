@@ -179,8 +179,9 @@ class Plan(object):
         if rows is None:
             rows = self.alloc_rows()
         cp = abi.c_params(params)
-        _lib.check(self.eng.L.smc_plan_run(self.h, ctypes.byref(cp), planes[0].data_ptr(), planes[1].data_ptr(),
-                                           planes[2].data_ptr(), planes[3].data_ptr(), planes[4].data_ptr(),
+        ptr = lambda t: t.data_ptr() if t is not None else None     # (umi / dist may be absent: the kernels do not read them)
+        _lib.check(self.eng.L.smc_plan_run(self.h, ctypes.byref(cp), ptr(planes[0]), ptr(planes[1]),
+                                           ptr(planes[2]), ptr(planes[3]), ptr(planes[4]),
                                            rows.data_ptr(), st_ptr), "smc_plan_run")
         return rows
 
