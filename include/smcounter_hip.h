@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SMC_ABI_VERSION 2
+#define SMC_ABI_VERSION 3
 #define SMC_MAX_ALLELES 64 /* allele ids per locus; ids 0-5 are A,T,G,C,N,'DEL' */
 
 /* error codes */
@@ -329,9 +329,11 @@ typedef struct smc_build_in {
     const smc_dev_aln* aln; const uint32_t* cig; const uint8_t* seq; const uint8_t* qual;
     const smc_dev_locus* loc; const uint8_t* refseq;
     int32_t start0, n_loci, n_bc, n_pair;
-    int32_t max_depth;   /* reads at the run's deepest locus (the caller counted them for loc[].n): sizes the scratch of loci
-                          * beyond the on-chip sort (8192 reads); 0 = no locus is deeper than that */
-    int32_t reserved;
+    int32_t max_depth;   /* reads at the run's deepest locus (the caller counted them for loc[].n); checked against
+                          * smc_build_max_depth() */
+    int32_t n_aln;       /* entries of aln[] (every loc[].w1 must stay within them); < 0: not checked */
+    const smc_dev_locus* loc_host; /* the same loc[] in HOST memory (the decoder fills it there): sizes the sort and the launch
+                                    * grids without a round trip; NULL = the library copies loc[] back itself (synchronous) */
 } smc_build_in;
 int smc_build_max_depth(void);
 int smc_build_planes(smc_ctx* ctx, const smc_params* params, const smc_build_in* in, uint32_t slot_base, uint32_t umi_base,

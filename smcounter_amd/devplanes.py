@@ -5,7 +5,8 @@ The per-pileup-read half of the reference's feature extraction and barcode bookk
 and whatever needs strings: the texts of indel alleles, the reference's down-sampling on barcode texts (:496-498, py2
 semantics).  A run the device path does not take (a locus deeper than smc_build_max_depth(), an alignment with neither
 READ1 nor READ2, an overflow the kernel reports) is built by the host builder (smc_bam_planes) and uploaded into the same
-device arrays - same planes either way (tests/test_gpu_parity.py compares them byte for byte).
+device arrays - the same batch either way up to the numbering of barcodes and fragments within a locus, which the layout
+contract leaves to the builder (planecheck.py; tests/test_gpu_devplanes.py compares them).
 """
 from __future__ import annotations
 
@@ -170,8 +171,9 @@ def _device_run(bam, L, eng, cp, params, chrom, lo, hi, max_reads, nthreads, fas
     xcap = 4 * nl + 4096
     d_x = DevBuf(eng, 20 * xcap)
     d_cnt = DevBuf(eng, 8)
+    loc_host = np.ascontiguousarray(A["loc"])          # (the windows size the sort and the launch grids: read on the host)
     bi = abi.SmcBuildIn(d_aln.data_ptr(), d_cig.data_ptr(), d_seq.data_ptr(), d_qual.data_ptr(), d_loc.data_ptr(), d_ref.data_ptr(),
-                        lo, nl, A["n_bc"], A["n_pair"], deepest, 0)
+                        lo, nl, A["n_bc"], A["n_pair"], deepest, len(A["aln"]), loc_host.ctypes.data)
     _lib.check(L.smc_build_planes(eng.ctx, ctypes.byref(cp), ctypes.byref(bi), slot_base, umi_base, planes[0].data_ptr(),
                                   planes[1].data_ptr() if planes[1] is not None else None, planes[2].data_ptr(),
                                   planes[3].data_ptr() if planes[3] is not None else None, uaux[0].data_ptr(),

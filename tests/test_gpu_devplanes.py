@@ -1,5 +1,5 @@
-"""The device plane builder (k_build_planes, through smc_bam_alignments + smc_build_planes) against the host builder
-(smc_bam_planes): the same planes byte for byte, the same descriptors, barcode boundaries, sampling marks and allele tables,
+"""The device plane builder (csrc/k_build_planes.inc, through smc_bam_alignments + smc_build_planes) against the host builder
+(smc_bam_planes): the same descriptors, barcodes, fragments, reads, sampling marks and allele tables,
 on random BAMs (CIGARs with S/M/I/D/N, two chromosomes, odd read names), the variant fixture, and under a barcode cap that
 triggers the reference's down-sampling; then the whole command line with planes built either way."""
 import os
@@ -17,19 +17,15 @@ pytestmark = pytest.mark.gpu
 
 
 def _same_batch(rb, hb):
-    """ResidentBatch (device-built, copied back) vs DeviceBatch (host-built)."""
+    """ResidentBatch (device-built, copied back) vs DeviceBatch (host-built): the same descriptors, the same barcodes with the
+    same fragments and the same reads in the same order within a fragment, the same sampling marks and allele tables.  The two
+    builders number the barcodes (and a barcode's fragments) of a locus differently - first appearance in the run vs at the
+    locus, both within the layout contract - so the comparison is on the order-free fingerprint of planecheck.py."""
+    from smcounter_amd import planecheck
     db = rb.to_host()
-    assert db.n_loci == hb.n_loci
-    for f in ("n_reads", "n_umi", "n_frag", "ref_allele", "n_alleles", "flags", "snp_mask", "read_off4"):
-        assert np.array_equal(db.loci[f], hb.loci[f]), f
-    for k in ("meta", "umi", "frag", "dist"):
-        x, y = getattr(db, k), getattr(hb, k)
-        assert x.dtype == y.dtype and np.array_equal(x, y), k
+    assert planecheck.differences(db, hb) == []
     for l in range(db.n_loci):
-        o1, o2, nu = int(db.loci["umi_off"][l]), int(hb.loci["umi_off"][l]), int(hb.loci["n_umi"][l])
-        assert np.array_equal(db.umi_start[o1:o1 + nu + 1], hb.umi_start[o2:o2 + nu + 1]), l
-    assert db.chrom == hb.chrom and db.ref == hb.ref and np.array_equal(db.pos, hb.pos)
-    assert db.alleles == hb.alleles
+        assert int(db.loci["umi_off"][l]) + int(db.loci["n_umi"][l]) + 1 <= len(db.umi_start)
 
 
 @pytest.mark.parametrize("mt_depth", [1000, 4])          # 4 -> ds = 8 < 25 barcodes: the py2 down-sampling marks
@@ -100,10 +96,9 @@ def test_runs_the_device_path_does_not_take_fall_back(engine0, tmp_path):
 
 @pytest.mark.parametrize("depth", [9000, 40000])
 def test_loci_deeper_than_the_on_chip_sort(engine0, tmp_path, depth):
-    """Loci beyond 8192 reads (the reference's own example run has 58 k per locus) take k_build_planes' second
-    instantiation - sort keys in global scratch, 8192-key stretches sorted in LDS, the wider compare-exchange steps on the
-    global array: the same bytes as the host builder, for loci either side of the limit in ONE run (shallow flanks, a deep
-    core), indel alleles, soft clips, pairs, and barcodes of very different sizes."""
+    """Deep loci (the reference's own example run has 58 k reads per locus; round 2's builder needed a second kernel beyond
+    8192): the same batch as the host builder for shallow flanks and a deep core in ONE run, indel alleles, soft clips, pairs,
+    and barcodes of very different sizes (a few giant ones: a part of the sorted list then begins inside a barcode)."""
     from smcounter_amd import devplanes
     rng = np.random.default_rng(depth)
     L = 400
