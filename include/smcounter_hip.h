@@ -281,6 +281,10 @@ void smc_destroy(smc_ctx* ctx);
  * apply_async task list, smCounter.py:684. */
 int smc_plan_create(smc_ctx* ctx, const smc_locus* loci, int64_t n_loci, smc_plan** out);
 void smc_plan_destroy(smc_plan* plan);
+/* The same plan for a batch whose descriptors are already on the DEVICE (smc_build_planes has just written them): the binning
+ * runs there, only a small record (and the few loci deep enough to be cut into parts) comes back.  Enqueued on `stream`
+ * behind whatever wrote `d_loci`; synchronises on it.  `d_loci` stays the caller's and must outlive the plan. */
+int smc_plan_create_dev(smc_ctx* ctx, const smc_locus* d_loci, int64_t n_loci, void* stream, smc_plan** out);
 /* number of kernel launches one smc_plan_run issues, and bytes of device scratch it holds */
 int smc_plan_info(const smc_plan* plan, int32_t* n_launches, int64_t* scratch_bytes);
 
@@ -326,7 +330,9 @@ int smc_unpack_rows(const smc_wire_row* wire, int64_t n, smc_row* rows);
  * 1 depth mismatch (a locus's reads differ from loc[].n, or exceed in->max_depth / smc_build_max_depth()), 2 extras overflow, 4 base quality > 126, 8 more
  * than 64 alleles) - the caller falls back to smc_bam_planes for the run when it is not 0.  Asynchronous on `stream`. */
 typedef struct smc_build_in {
-    const smc_dev_aln* aln; const uint32_t* cig; const uint8_t* seq; const uint8_t* qual;
+    const smc_dev_aln* aln; const uint32_t* cig;
+    const uint8_t* seq; const uint8_t* qual;   /* 16-byte aligned, and readable 16 bytes past their last entry: the builder
+                                                * fetches bases and qualities 16 bytes a load */
     const smc_dev_locus* loc; const uint8_t* refseq;
     int32_t start0, n_loci, n_bc, n_pair;
     int32_t max_depth;   /* reads at the run's deepest locus (the caller counted them for loc[].n); checked against
@@ -336,6 +342,11 @@ typedef struct smc_build_in {
                                     * grids without a round trip; NULL = the library copies loc[] back itself (synchronous) */
 } smc_build_in;
 int smc_build_max_depth(void);
+/* Optional: bracket the walk that writes the planes (k_bp_tiles<true>, the dominant kernel of smc_build_planes) with a HIP event
+ * pair on the run's stream, in a ring of `slots` pairs (0 disables); smc_build_kernel_ms synchronises on the recorded pairs and
+ * returns that launch's mean duration over the last min(runs, slots) calls. */
+int smc_build_set_timing(smc_ctx* ctx, int slots);
+int smc_build_kernel_ms(smc_ctx* ctx, float* avg_ms, int32_t* n_samples);
 int smc_build_planes(smc_ctx* ctx, const smc_params* params, const smc_build_in* in, uint32_t slot_base, uint32_t umi_base,
                      uint32_t* meta, uint32_t* umi, uint32_t* frag, uint32_t* dist, uint32_t* umi_start, uint32_t* u_gid,
                      uint32_t* u_finc, smc_locus* loci, uint32_t* xlist, uint32_t xcap, uint32_t* counters, void* stream);

@@ -32,7 +32,7 @@ A = bam.alignments_run(chrom, lo, hi, 1 << 40, P, len(os.sched_getaffinity(0)), 
 nl, ns = A["nl"], A["n_slots"]
 reads = int(A["loc"]["n"].sum())
 print("run: %d loci, %d alignments, %d pileup reads, %d barcodes, %d fragments" % (nl, len(A["aln"]), reads, A["n_bc"], A["n_pair"]))
-up = lambda a: DevBuf(eng, max(4, a.nbytes)).upload(a.view(np.uint8).reshape(-1))
+up = lambda a: DevBuf(eng, a.nbytes + 64).upload(a.view(np.uint8).reshape(-1))
 d_aln, d_cig, d_seq, d_qual, d_loc = up(A["aln"]), up(A["cig"]), up(A["seq"]), up(A["qual"]), up(A["loc"])
 run_ref = ref_f.fetch(chrom, lo, hi).upper()
 d_ref = up(np.frombuffer(run_ref[:nl].encode().ljust(nl, b"\0"), np.uint8).copy())

@@ -11,10 +11,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsmcounter_hip.so")
 
 SYMBOLS = ("smc_abi_version", "smc_last_error", "smc_row_size", "smc_locus_size", "smc_device_count",
-           "smc_create", "smc_destroy", "smc_plan_create", "smc_plan_destroy", "smc_plan_info",
+           "smc_create", "smc_destroy", "smc_plan_create", "smc_plan_create_dev", "smc_plan_destroy", "smc_plan_info",
            "smc_plan_run", "smc_plan_set_timing", "smc_plan_kernel_ms", "smc_call_batch_host", "smc_event_create", "smc_event_record",
            "smc_event_elapsed_ms", "smc_event_destroy", "smc_class_table", "smc_wire_row_size", "smc_pack_rows", "smc_unpack_rows",
-           "smc_build_planes", "smc_build_max_depth", "smc_mem_alloc", "smc_mem_free", "smc_mem_h2d", "smc_mem_d2h",
+           "smc_build_planes", "smc_build_max_depth", "smc_build_set_timing", "smc_build_kernel_ms", "smc_mem_alloc", "smc_mem_free", "smc_mem_h2d", "smc_mem_d2h",
            "smc_mem_alloc_host", "smc_mem_free_host",
            "smc_device_sync")
 
@@ -59,6 +59,7 @@ def load(with_torch: bool = True):
     L.smc_destroy.argtypes = [vp]
     L.smc_destroy.restype = None
     L.smc_plan_create.argtypes = [vp, vp, i64, ctypes.POINTER(vp)]
+    L.smc_plan_create_dev.argtypes = [vp, vp, i64, vp, ctypes.POINTER(vp)]
     L.smc_plan_destroy.argtypes = [vp]
     L.smc_plan_destroy.restype = None
     L.smc_plan_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i64)]
@@ -80,6 +81,8 @@ def load(with_torch: bool = True):
     L.smc_mem_d2h.argtypes = [vp, vp, vp, i64]
     L.smc_device_sync.argtypes = [vp]
     L.smc_build_max_depth.restype = ctypes.c_int
+    L.smc_build_set_timing.argtypes = [vp, ctypes.c_int]
+    L.smc_build_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32)]
     L.smc_build_planes.argtypes = [vp, ctypes.POINTER(abi.SmcParams), ctypes.POINTER(abi.SmcBuildIn), ctypes.c_uint32,
                                    ctypes.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_uint32, vp, vp]
     L.smc_event_create.argtypes = [ctypes.POINTER(vp)]

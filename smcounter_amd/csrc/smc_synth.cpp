@@ -234,3 +234,191 @@ int smc_synth_generate(const smc_synth_cfg* c, int64_t lo, int64_t hi, uint32_t*
 }
 
 }  // extern "C"
+
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------------------------
+// Synthetic ALIGNMENTS of stated depth (round 3): the input of the device plane builder (smc_build_planes) in the form the
+// BAM decoder hands it over (smc_bam_alignments: smc_dev_aln records, CIGAR / base / quality pools, per-locus windows), for
+// bench.py's `from_alignments` leg - the hot path timed from where the reference's hot loop starts (smCounter.py:316), not
+// from planes that are already sorted and classified.
+// Shape: molecules (barcodes) start every L / n_umi positions (L = mean read length 125), so a locus is covered by ~ n_umi
+// barcodes; a molecule has `rpb` reads - a fraction p_overlap of its fragments as mate pairs (R1 forward + R2 reverse), the
+// rest single - all starting within 4 positions of the molecule's start, 100-150 bases long: depth ~ n_umi x rpb.  Reference
+// base at 1-based position p is "ACGT"[p % 4]; per-base sequencing error p_err; qualities / MAPQ / mismatch counts from the
+// distributions of the pileup generator above; 5 % of the alignments begin with a soft clip, p_ins_aln carry a one-base
+// insertion, p_del_aln a two-base deletion.  Alignments come out in coordinate order with run-wide barcode / fragment ids
+// numbered by first appearance, exactly as the decoder numbers them.  Deterministic for a given (seed, shape), whatever
+// the thread count.
+typedef struct smc_synth_acfg {
+    int64_t n_loci, start0;      // loci [start0, start0 + n_loci), 0-based
+    int32_t n_umi, rpb;
+    uint64_t seed;
+    double p_overlap, p_err, p_ins_aln, p_del_aln, p_clip, mismatch_thr;
+} smc_synth_acfg;
+typedef void (*smc_aln_alloc)(void* ctx, int64_t n_aln, int64_t n_cig, int64_t n_seq, int64_t n_loci, void** out);
+
+int64_t smc_synth_alignments(const smc_synth_acfg* c, smc_aln_alloc alloc, void* alloc_ctx, int64_t* n_slots, int32_t* n_bc_out,
+                             int32_t* n_pair_out, int nthreads) {
+    struct A { int32_t pos, len; uint32_t mol; uint16_t frag; uint8_t flag /* 1 R1, 2 R2, 4 reverse */, kind /* 0 plain, 1 clip, 2 ins, 3 del */; uint8_t clip, mapq; uint16_t mism; uint64_t seed; };
+    const double L = 125.0;
+    const int64_t lead = 160;                                    // molecules start this far before the first locus
+    const int64_t n_mol = (int64_t)((double)(c->n_loci + lead) * c->n_umi / L) + 1;
+    const int B = c->rpb;
+    const int f0 = std::max(1, (int)llround(B / (1.0 + c->p_overlap)));
+    nthreads = std::max(1, nthreads);
+    std::vector<std::vector<A>> per_thread((size_t)nthreads);
+    {
+        std::vector<std::thread> th;
+        const int64_t per = (n_mol + nthreads - 1) / nthreads;
+        for (int t = 0; t < nthreads; ++t)
+            th.emplace_back([&, t]() {
+                std::vector<A>& out = per_thread[(size_t)t];
+                for (int64_t m = t * per; m < std::min(n_mol, (t + 1) * per); ++m) {
+                    Rng g(c->seed ^ 0xA11C0DEull, (uint64_t)m);
+                    const int64_t s = c->start0 - lead + (int64_t)((double)m * L / c->n_umi);
+                    int k = 0;
+                    for (int t2 = 0; t2 < f0; ++t2) k += g.uni() < c->p_overlap;
+                    k = std::min(k, B / 2);
+                    for (int j = 0; j < B; ++j) {
+                        A a;
+                        const bool in_pair = j < 2 * k;
+                        a.frag = (uint16_t)(in_pair ? j / 2 : j - k);
+                        const bool r2 = in_pair ? (j & 1) : (g.uni() < 0.5);
+                        const bool rev = r2 ^ (g.uni() < 0.1);
+                        a.flag = (uint8_t)((r2 ? 2 : 1) | (rev ? 4 : 0));
+                        a.pos = (int32_t)(s + (int64_t)g.below(4));
+                        a.len = 100 + (int)g.below(51);
+                        const double ev = g.uni();
+                        a.kind = ev < c->p_clip ? 1 : ev < c->p_clip + c->p_ins_aln ? 2 : ev < c->p_clip + c->p_ins_aln + c->p_del_aln ? 3 : 0;
+                        a.clip = (uint8_t)(1 + g.below(10));
+                        a.mapq = g.uni() < 0.02 ? 20 : 60;
+                        const double mx = g.uni();
+                        a.mism = (uint16_t)(g.uni() < 0.01 ? 8 : (mx < .8 ? 0 : (mx < .95 ? 1 : 2)));
+                        a.mol = (uint32_t)m;
+                        a.seed = g.next();
+                        if (a.pos < 0) continue;
+                        out.push_back(a);
+                    }
+                }
+            });
+        for (auto& t : th) t.join();
+    }
+    // coordinate order, stable in (molecule, read): a counting sort by start position
+    int64_t n_aln = 0;
+    for (auto& v : per_thread) n_aln += (int64_t)v.size();
+    const int64_t p_lo = c->start0 - lead, span = c->n_loci + lead + 8;
+    std::vector<int64_t> first((size_t)span + 1, 0);
+    for (auto& v : per_thread) for (const A& a : v) if (a.pos - p_lo < span) ++first[(size_t)(a.pos - p_lo) + 1];
+    for (int64_t i = 0; i < span; ++i) first[(size_t)i + 1] += first[(size_t)i];
+    n_aln = first[(size_t)span];
+    std::vector<A> al((size_t)n_aln);
+    {
+        std::vector<int64_t> cur(first.begin(), first.end() - 1);
+        for (auto& v : per_thread) { for (const A& a : v) if (a.pos - p_lo < span) al[(size_t)cur[(size_t)(a.pos - p_lo)]++] = a; std::vector<A>().swap(v); }
+    }
+    // run-wide ids by first appearance (the decoder's numbering), CIGAR / base offsets, reference span
+    std::vector<int32_t> bc_of((size_t)n_mol, -1);
+    std::vector<int32_t> pair_first((size_t)n_mol * (size_t)B, -1);
+    std::vector<uint32_t> bc_gid((size_t)n_aln), pair_gid((size_t)n_aln), offc((size_t)n_aln + 1, 0), offs((size_t)n_aln + 1, 0);
+    std::vector<int32_t> endp((size_t)n_aln);
+    int32_t n_bc = 0, n_pair = 0;
+    for (int64_t i = 0; i < n_aln; ++i) {
+        const A& a = al[(size_t)i];
+        if (bc_of[a.mol] < 0) bc_of[a.mol] = n_bc++;
+        int32_t& pf = pair_first[(size_t)a.mol * (size_t)B + a.frag];
+        if (pf < 0) pf = n_pair++;
+        bc_gid[(size_t)i] = (uint32_t)bc_of[a.mol]; pair_gid[(size_t)i] = (uint32_t)pf;
+        offc[(size_t)i + 1] = offc[(size_t)i] + (a.kind == 0 ? 1u : a.kind == 1 ? 2u : 3u);
+        offs[(size_t)i + 1] = offs[(size_t)i] + (uint32_t)a.len;
+        // reference span: kind 1: len - clip; kind 2: len - 1 (one inserted base); kind 3: len + 2 (two deleted)
+        endp[(size_t)i] = a.pos + (a.kind == 1 ? a.len - a.clip : a.kind == 2 ? a.len - 1 : a.kind == 3 ? a.len + 2 : a.len);
+    }
+    // depth per locus, slots
+    std::vector<int64_t> cov((size_t)c->n_loci + 1, 0);
+    const int64_t s0 = c->start0, e0 = c->start0 + c->n_loci;
+    for (int64_t i = 0; i < n_aln; ++i) {
+        const int64_t lo = std::max<int64_t>(al[(size_t)i].pos, s0), hi = std::min<int64_t>(endp[(size_t)i], e0);
+        if (lo < hi) { ++cov[(size_t)(lo - s0)]; --cov[(size_t)(hi - s0)]; }
+    }
+    void* bufs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    alloc(alloc_ctx, n_aln, (int64_t)offc[(size_t)n_aln], (int64_t)offs[(size_t)n_aln], c->n_loci, bufs);
+    smc_dev_aln* pa = (smc_dev_aln*)bufs[0]; uint32_t* pc = (uint32_t*)bufs[1];
+    uint8_t* ps = (uint8_t*)bufs[2]; uint8_t* pq = (uint8_t*)bufs[3]; smc_dev_locus* pl = (smc_dev_locus*)bufs[4];
+    if (!pa || !pc || !ps || !pq || !pl) return -9;
+    int64_t slots = 0, total = 0, run = 0;
+    {
+        size_t w0 = 0, w1 = 0;
+        for (int64_t l = 0; l < c->n_loci; ++l) {
+            run += cov[(size_t)l];
+            total += run;
+            const int64_t p0 = s0 + l;
+            while (w0 < (size_t)n_aln && endp[w0] <= p0) ++w0;
+            while (w1 < (size_t)n_aln && al[w1].pos <= p0) ++w1;
+            pl[l].w0 = (uint32_t)w0; pl[l].w1 = (uint32_t)std::max(w0, w1);
+            pl[l].slot_off = (uint32_t)slots; pl[l].n = (uint32_t)run;
+            slots += (run + 3) / 4 * 4;
+        }
+    }
+    if (slots >= (1ll << 32)) return -10;
+    // records and pools, in parallel by alignment
+    {
+        static const char REF[5] = "ACGT";
+        static const uint8_t bqv[5] = {12, 25, 30, 37, 40};
+        // quality by one byte of a random word: cumulative thresholds of {.03, .07, .2, .4, .3} over 256
+        uint8_t qlut[256];
+        for (int v = 0; v < 256; ++v) { const double x = (v + 0.5) / 256.0; qlut[v] = bqv[x < .03 ? 0 : x < .10 ? 1 : x < .30 ? 2 : x < .70 ? 3 : 4]; }
+        std::vector<std::thread> th;
+        const int64_t per = (n_aln + nthreads - 1) / nthreads;
+        for (int t = 0; t < nthreads; ++t)
+            th.emplace_back([&, t]() {
+                for (int64_t i = t * per; i < std::min(n_aln, (t + 1) * per); ++i) {
+                    const A& a = al[(size_t)i];
+                    Rng g(a.seed, (uint64_t)i);
+                    smc_dev_aln& d = pa[i];
+                    d.pos = a.pos; d.end = endp[(size_t)i];
+                    d.cig_off = offc[(size_t)i]; d.seq_off = offs[(size_t)i];
+                    d.n_cig = (uint16_t)(offc[(size_t)i + 1] - offc[(size_t)i]);
+                    const double mm100 = 100.0 * (double)a.mism / (double)a.len;                    // smCounter.py:352-356
+                    d.oflag = (uint8_t)((a.flag & 7) | (mm100 <= c->mismatch_thr ? SMC_DA_MMOK : 0));
+                    d.mapq = a.mapq;
+                    d.left_sp = (uint16_t)(a.kind == 1 ? a.clip : 0);
+                    d.qalen = (uint16_t)(a.len - (a.kind == 1 ? a.clip : 0));
+                    d.l_seq = (uint16_t)a.len; d.pad = 0;
+                    d.bc_gid = bc_gid[(size_t)i]; d.pair_gid = pair_gid[(size_t)i];
+                    uint32_t* cg = pc + offc[(size_t)i];
+                    const int half = a.len / 2;
+                    if (a.kind == 0) cg[0] = (uint32_t)a.len << 4;
+                    else if (a.kind == 1) { cg[0] = (uint32_t)a.clip << 4 | 4u; cg[1] = (uint32_t)(a.len - a.clip) << 4; }
+                    else if (a.kind == 2) { cg[0] = (uint32_t)half << 4; cg[1] = 1u << 4 | 1u; cg[2] = (uint32_t)(a.len - half - 1) << 4; }
+                    else { cg[0] = (uint32_t)half << 4; cg[1] = 2u << 4 | 2u; cg[2] = (uint32_t)(a.len - half) << 4; }
+                    // bases: the reference under every query position (clips and the inserted base: a random letter), errors rare
+                    uint8_t* sq = ps + offs[(size_t)i];
+                    uint8_t* ql = pq + offs[(size_t)i];
+                    int64_t rp = a.pos + 1;                              // 1-based reference position of the next match
+                    for (int q = 0; q < a.len; ++q) {
+                        bool off_ref = (a.kind == 1 && q < a.clip) || (a.kind == 2 && q == half);
+                        if (a.kind == 3 && q == half) rp += 2;           // the two deleted bases
+                        sq[q] = (uint8_t)(off_ref ? REF[g.below(4)] : REF[rp & 3]);
+                        if (!off_ref) ++rp;
+                    }
+                    // sequencing errors by geometric skipping
+                    if (c->p_err > 0) {
+                        const double lg = log1p(-c->p_err);
+                        for (int q = (int)(log(1.0 - g.uni()) / lg); q < a.len; q += 1 + (int)(log(1.0 - g.uni()) / lg))
+                            sq[q] = (uint8_t)REF[((sq[q] == 'A' ? 0 : sq[q] == 'C' ? 1 : sq[q] == 'G' ? 2 : 3) + 1 + (int)g.below(3)) & 3];
+                    }
+                    for (int q = 0; q < a.len; q += 8) {
+                        uint64_t w = g.next();
+                        for (int b = 0; b < 8 && q + b < a.len; ++b, w >>= 8) ql[q + b] = qlut[w & 255];
+                    }
+                }
+            });
+        for (auto& t : th) t.join();
+    }
+    *n_slots = slots; *n_bc_out = n_bc; *n_pair_out = n_pair;
+    return total;
+}
+
+}  // extern "C"

@@ -152,10 +152,23 @@ def _device_run(bam, L, eng, cp, params, chrom, lo, hi, max_reads, nthreads, fas
     """One run through smc_bam_alignments + smc_build_planes.  -> (n loci, slots, descriptors, allele tables) or None
     when the run has to take the host builder."""
     import time
-    from .engine import DevBuf
     T = _TIMES if os.environ.get("SMC_DEVPLANES_TIMING") else None
     t0 = time.perf_counter()
     A = bam.alignments_run(chrom, lo, hi, max_reads, params, nthreads, host_array=eng.pinned)
+    if T is not None:
+        T["decode"] += time.perf_counter() - t0
+    return build_run(A, L, eng, cp, params, chrom, lo, fasta, run_ref, planes, uaux, slot_base, umi_base, cap, max_depth,
+                     bam.allele_key, bam.barcode_name)
+
+
+def build_run(A, L, eng, cp, params, chrom, lo, fasta, run_ref, planes, uaux, slot_base, umi_base, cap, max_depth,
+              allele_key, barcode_name, stream_sync=True):
+    """smc_build_planes over one run's alignments `A` (bamio.NativeBam.alignments_run or synth.generate_alignments) into the
+    batch's device arrays.  `allele_key(ai, qpos, indel)` / `barcode_name(gid)` give the texts the host needs (indel allele
+    keys, barcode names for the reference's down-sampling)."""
+    import time
+    from .engine import DevBuf
+    T = _TIMES if os.environ.get("SMC_DEVPLANES_TIMING") else None
     t1 = time.perf_counter()
     nl, ns = A["nl"], A["n_slots"]
     if nl == 0:
@@ -164,7 +177,7 @@ def _device_run(bam, L, eng, cp, params, chrom, lo, hi, max_reads, nthreads, fas
     if A["status"] != 0 or deepest > max_depth or slot_base + ns > cap or \
             umi_base + ns + nl + 1 > cap + 8192:
         return None
-    up = lambda a: DevBuf(eng, max(4, a.nbytes)).upload(a.view(np.uint8).reshape(-1) if a.nbytes else np.zeros(4, np.uint8))
+    up = lambda a: DevBuf(eng, a.nbytes + 64).upload(a.view(np.uint8).reshape(-1) if a.nbytes else np.zeros(4, np.uint8))
     d_aln, d_cig, d_seq, d_qual, d_loc = up(A["aln"]), up(A["cig"]), up(A["seq"]), up(A["qual"]), up(A["loc"])
     d_ref = up(np.frombuffer(run_ref[:nl].encode().ljust(nl, b"\0"), np.uint8).copy())
     d_loci = DevBuf(eng, nl * LOCUS_DTYPE.itemsize)
@@ -183,7 +196,7 @@ def _device_run(bam, L, eng, cp, params, chrom, lo, hi, max_reads, nthreads, fas
     cnt = d_cnt.download(np.uint32, 2)        # (a copy on the default stream: behind the kernel)
     t3 = time.perf_counter()
     if T is not None:
-        T["decode"] += t1 - t0; T["upload+launch"] += t2 - t1; T["kernel (sync)"] += t3 - t2
+        T["upload+launch"] += t2 - t1; T["kernel (sync)"] += t3 - t2
     if int(cnt[1]) != 0 or int(cnt[0]) > xcap:
         if int(cnt[1]) & 4:
             from .features import PileupError
@@ -199,7 +212,7 @@ def _device_run(bam, L, eng, cp, params, chrom, lo, hi, max_reads, nthreads, fas
         xl = d_x.download(np.uint32, 5 * nx).reshape(nx, 5)
         xl = xl[np.lexsort((xl[:, 1], xl[:, 0]))]
         for l, aid, ai, qpos, indel in xl.tolist():
-            key = bam.allele_key(ai, qpos, np.int32(np.uint32(indel)))
+            key = allele_key(ai, qpos, np.int32(np.uint32(indel)))
             if key[0] == "D" and len(key) > 1:        # "D<len>|<site>" -> DEL|site+deleted|site (smCounter.py:392-396)
                 ln, site = key[1:].split("|")
                 pos1 = lo + l + 1
@@ -208,6 +221,7 @@ def _device_run(bam, L, eng, cp, params, chrom, lo, hi, max_reads, nthreads, fas
                 tables[l] = list(BASE_ALLELES)
             assert aid == len(tables[l]), (l, aid, len(tables[l]))
             tables[l].append(key)
+    d_x.free()
     # the reference's down-sampling (smCounter.py:496-498) on loci over the barcode cap: barcode texts by first included read
     over = np.nonzero(lc["n_umi"] > params.ds)[0] if params.ds > 0 else []
     if len(over):
@@ -221,7 +235,7 @@ def _device_run(bam, L, eng, cp, params, chrom, lo, hi, max_reads, nthreads, fas
             keys = keys[np.argsort(finc[keys], kind="stable")]
             if len(keys) <= params.ds:
                 continue
-            names = [bam.barcode_name(int(gid[u])) for u in keys]
+            names = [barcode_name(int(gid[u])) for u in keys]
             kept = set(py2_downsample_barcodes(str(lo + l + 1), names, params.ds))
             for u, name in zip(keys.tolist(), names):
                 if name not in kept:
@@ -229,3 +243,48 @@ def _device_run(bam, L, eng, cp, params, chrom, lo, hi, max_reads, nthreads, fas
             uaux[0].upload(us, 4 * o)
             lc["flags"][l] |= LF_SAMPLED
     return nl, ns, lc, tables
+
+
+def synth_allele_key(A):
+    """`allele_key` for a run of synth.generate_alignments (what smc_bam_allele_key answers for a decoded run)."""
+    def key(ai, qpos, indel):
+        a = A["aln"][int(ai)]
+        so, ls = int(a["seq_off"]), int(a["l_seq"])
+        site = chr(A["seq"][so + int(qpos)])
+        indel = int(indel)
+        if indel > 0:
+            return "INS|%s|%s%s" % (site, site, A["seq"][so + int(qpos) + 1:so + min(ls, int(qpos) + 1 + indel)].tobytes().decode())
+        if indel < 0:
+            return "D%d|%s" % (-indel, site)
+        return site
+    return key
+
+
+def resident_from_alignments(A, eng, params, all_planes: bool = True, chrom: str = None) -> ResidentBatch:
+    """One run of synthetic alignments (synth.generate_alignments) -> a ResidentBatch built by smc_build_planes; raises when
+    the device path does not take the run."""
+    from . import synth
+    from .engine import DevBuf
+    L = eng.L
+    chrom = chrom or synth.ALN_CHROM
+    nl, ns, lo = A["nl"], A["n_slots"], int(A["start0"])
+    cap = ns + 64
+    planes = [DevBuf(eng, 4 * cap) if (all_planes or k in (0, 2)) else None for k in range(4)]
+    uaux = [DevBuf(eng, 4 * (cap + nl + 8192)) for _ in range(3)]
+    run_ref = synth.aln_ref_fetch(lo, lo + nl)
+    ref = synth.CyclicRef()
+    done = build_run(A, L, eng, abi.c_params(params), params, chrom, lo, ref, run_ref, planes, uaux, 0, 0, cap + nl,
+                     L.smc_build_max_depth(), synth_allele_key(A), lambda gid: "B%d" % gid)
+    if done is None:
+        raise RuntimeError("smc_build_planes did not take the run (status / size)")
+    nl, ns, lc, tb = done
+    uaux[1].free(); uaux[2].free()
+    return ResidentBatch(planes=planes + [uaux[0]], n_slots=ns, n_ustart=ns + nl + 1, loci=lc, chrom=[chrom] * nl,
+                         pos=np.arange(lo + 1, lo + 1 + nl, dtype=np.int64), ref=list(run_ref), alleles=tb, n_device_runs=1)
+
+
+def DevLoci(eng, loci: np.ndarray):
+    """The descriptors of a batch uploaded as a device array (for engine.make_plan_dev)."""
+    from .engine import DevBuf
+    loci = np.ascontiguousarray(loci)
+    return DevBuf(eng, max(32, loci.nbytes)).upload(loci.view(np.uint8).reshape(-1))

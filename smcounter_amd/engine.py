@@ -153,6 +153,15 @@ class Engine(object):
         return Plan(self, h, len(loci))
 
 
+    def make_plan_dev(self, d_loci, n_loci: int):
+        """The plan of a batch whose descriptors are in HBM (`d_loci`: DevBuf / tensor of smc_locus, e.g. what smc_build_planes
+        wrote): binned on the device (smc_plan_create_dev), default stream.  `d_loci` must outlive the plan."""
+        h = ctypes.c_void_p()
+        _lib.check(self.L.smc_plan_create_dev(self.ctx, d_loci.data_ptr(), int(n_loci), ctypes.c_void_p(0), ctypes.byref(h)),
+                   "smc_plan_create_dev")
+        return Plan(self, h, int(n_loci))
+
+
 class Plan(object):
     def __init__(self, eng: Engine, handle, n_loci: int):
         self.eng, self.h, self.n_loci = eng, handle, n_loci

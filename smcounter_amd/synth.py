@@ -477,3 +477,90 @@ def generate_native(cfg: SynthConfig, lo: int = 0, hi: int = None, params=None, 
             alleles[l] = base + [del_s]
     return DeviceBatch(loci=loci, meta=planes[0], umi=planes[1], frag=planes[2], dist=planes[3],
                        umi_start=umi_start, chrom=[cfg.chrom] * n, pos=pos, ref=ref, alleles=alleles)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Synthetic ALIGNMENTS (the input of the device plane builder): csrc/smc_synth.cpp smc_synth_alignments
+ALN_CHROM = "chrS"
+
+
+def aln_ref_fetch(start: int, end: int) -> str:
+    """Reference letters of 0-based [start, end): 1-based position p holds "ACGT"[p % 4] (CyclicRef)."""
+    p = np.arange(start + 1, end + 1)
+    return "".join(_LETTERS[i] for i in (p % 4))
+
+
+def generate_alignments(cfg: SynthConfig, n_loci: int = None, params=None, nthreads: int = 0, host_array=None,
+                        p_ins_aln: float = 0.02, p_del_aln: float = 0.02, p_clip: float = 0.05):
+    """A run of `n_loci` consecutive loci at cfg's depth shape (n_umi barcodes x rpb reads per locus) as the decoder would hand
+    it to smc_build_planes: dict(aln, cig, seq, qual, loc, nl, n_slots, n_bc, n_pair, status, reads, start0).
+    `host_array(name, dtype, count)` may provide the arrays (page-locked staging)."""
+    import ctypes as C
+    import os
+    from . import build
+    from .abi import DEV_ALN_DTYPE, DEV_LOCUS_DTYPE
+
+    class ACfg(C.Structure):
+        _fields_ = [("n_loci", C.c_int64), ("start0", C.c_int64), ("n_umi", C.c_int32), ("rpb", C.c_int32), ("seed", C.c_uint64),
+                    ("p_overlap", C.c_double), ("p_err", C.c_double), ("p_ins_aln", C.c_double), ("p_del_aln", C.c_double),
+                    ("p_clip", C.c_double), ("mismatch_thr", C.c_double)]
+
+    n_loci = cfg.n_loci if n_loci is None else n_loci
+    params = params or params_for(cfg)
+    lib = C.CDLL(build.build_synth())
+    alloc_t = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_void_p))
+    lib.smc_synth_alignments.restype = C.c_int64
+    lib.smc_synth_alignments.argtypes = [C.POINTER(ACfg), alloc_t, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                                         C.POINTER(C.c_int32), C.c_int]
+    got = {}
+    mk = host_array or (lambda name, dtype, count: np.empty(count, dtype))
+
+    def alloc(ctx, n_aln, n_cig, n_seq, nl, out):
+        got["aln"] = mk("aln", DEV_ALN_DTYPE, n_aln)
+        got["cig"] = mk("cig", np.uint32, max(1, n_cig))
+        got["seq"] = mk("seq", np.uint8, max(1, n_seq))
+        got["qual"] = mk("qual", np.uint8, max(1, n_seq))
+        got["loc"] = mk("loc", DEV_LOCUS_DTYPE, nl)
+        for k, name in enumerate(("aln", "cig", "seq", "qual", "loc")):
+            out[k] = got[name].ctypes.data
+    start0 = cfg.start_pos - 1                                     # the pileup generator's first locus, 0-based
+    c = ACfg(n_loci, start0, cfg.n_umi, cfg.rpb, cfg.seed, cfg.p_overlap, cfg.p_err, p_ins_aln, p_del_aln, p_clip,
+             float(params.mismatchThr))
+    n_slots, n_bc, n_pair = C.c_int64(0), C.c_int32(0), C.c_int32(0)
+    nthreads = nthreads or min(32, len(os.sched_getaffinity(0)))
+    n = lib.smc_synth_alignments(C.byref(c), alloc_t(alloc), None, C.byref(n_slots), C.byref(n_bc), C.byref(n_pair), nthreads)
+    if n < 0:
+        raise RuntimeError("smc_synth_alignments failed (%d)" % n)
+    got.update(nl=n_loci, n_slots=n_slots.value, n_bc=n_bc.value, n_pair=n_pair.value, status=0, reads=n, start0=start0)
+    return got
+
+
+def alignments_to_bam(A: dict, path: str, l0: int, l1: int, fasta_path: str = None):
+    """Write the alignments of run `A` that cover loci [l0, l1) as a BAM (+ .bai, and the cyclic reference as a FASTA when asked):
+    the same reads through the real decoder - what bench.py checks the device plane builder against.  -> (chrom, first
+    1-based position, last)."""
+    from . import bamio
+    w0, w1 = int(A["loc"]["w0"][l0]), int(A["loc"]["w1"][l1 - 1])
+    recs = []
+    aln, cig, seq, qual = A["aln"], A["cig"], A["seq"], A["qual"]
+    for i in range(w0, w1):
+        a = aln[i]
+        ops = [(int(w) & 15, int(w) >> 4) for w in cig[int(a["cig_off"]):int(a["cig_off"]) + int(a["n_cig"])]]
+        n_ind = sum(l for op, l in ops if op in (1, 2))
+        so, ls = int(a["seq_off"]), int(a["l_seq"])
+        # mismatches the generator meant (it sets the mismatch-ok bit from them): 0 when ok, else above any threshold
+        fl = int(a["oflag"])
+        mism = 0 if fl & 16 else 200
+        recs.append(dict(tid=0, pos=int(a["pos"]), qname="q%d:x:B%d:y" % (int(a["pair_gid"]), int(a["bc_gid"])),
+                         flag=(0x40 if fl & 1 else 0x80) | (0x10 if fl & 4 else 0) | 1, mapq=int(a["mapq"]), cigar=ops,
+                         seq=seq[so:so + ls].tobytes().decode(), qual=qual[so:so + ls].tolist(), nm=min(255, mism + n_ind)))
+    end = int(A["start0"]) + int(A["nl"]) + 400
+    bamio.write_bam(path, [(ALN_CHROM, end)], recs)
+    bamio.write_bai(path)
+    if fasta_path:
+        with open(fasta_path, "w") as fh:
+            fh.write(">%s\n" % ALN_CHROM)
+            s = aln_ref_fetch(0, end)
+            for i in range(0, len(s), 60):
+                fh.write(s[i:i + 60] + "\n")
+    return ALN_CHROM, int(A["start0"]) + l0 + 1, int(A["start0"]) + l1

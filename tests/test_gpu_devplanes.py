@@ -183,3 +183,73 @@ def test_cli_device_and_host_planes_write_the_same_files(tmp_path, monkeypatch):
                       refGenome=case["fasta"], threshold=10))
         outs.append(open(prefix + ".smCounter.all.txt").read())
     assert outs[0] == outs[1] and outs[0].count("\n") > 10
+
+
+@pytest.mark.parametrize("name,n_loci", [("C2", 900), ("C3", 260), ("X2", 130)])
+def test_synthetic_alignments_through_the_device_builder_and_through_the_decoder(engine0, tmp_path, name, n_loci):
+    """bench.py's `from_alignments` input (synth.generate_alignments: the decoder's output format, made without a BAM) built
+    by smc_build_planes, against the SAME alignments written as a BAM and taken through the real decoder and the host
+    builder: equivalent planes, equal row strings, and the device-built batch's rows against the CPU restatement run on the
+    host-built planes."""
+    import oracle_lib
+    from smcounter_amd import devplanes, rows, synth, vc
+    cfg = synth.CONFIGS[name]
+    P = synth.params_for(cfg)
+    A = synth.generate_alignments(cfg, n_loci, P, p_ins_aln=0.03, p_del_aln=0.03)
+    assert A["n_slots"] > 0 and int(A["loc"]["n"].min()) > 0
+    rb = devplanes.resident_from_alignments(A, engine0, P)
+    bam, fa_path = str(tmp_path / "s.bam"), str(tmp_path / "s.fa")
+    chrom, p0, p1 = synth.alignments_to_bam(A, bam, 0, n_loci, fa_path)
+    fa = fasta.FastaFile(fa_path)
+    loci = [(chrom, str(p)) for p in range(p0, p1 + 1)]
+    host = [b for _, b in bamio.iter_device_batches_native(bam, fa, loci, P, max_reads=1 << 40)]
+    assert len(host) == 1
+    hb = host[0]
+    _same_batch(rb, hb)
+    assert any(len(t) > 6 for t in hb.alleles)
+    got = vc.vc_resident(rb, P, fa, engine0)
+    assert got == rows.format_rows(engine0.call_batch_host(hb, P), hb, P, fa)
+    plan = engine0.make_plan(rb.loci)
+    dev_rows = plan.run_devbuf(rb.planes, P)
+    plan.close()
+    want, fragile, pi_all = oracle_lib.call_batch(hb, abi.c_params(P), abi.ROW_DTYPE, return_fragile=True, return_pi_all=True)
+    assert abi.compare_rows(dev_rows, want, 1e-6, 1e-6, fragile, pi_all) == []
+
+
+def test_plan_made_on_the_device_gives_the_same_rows(engine0, tmp_path):
+    """smc_plan_create_dev (descriptors classified and the launch lists written on the device) against smc_plan_create (host):
+    identical row bytes - on a run that mixes every workgroup class (shallow flanks, a core beyond 24,576 reads: the deep class)
+    and on a synthetic panel shape."""
+    import test_bamio
+    from smcounter_amd import devplanes, synth
+    cases = []
+    cfg = synth.CONFIGS["C3"]
+    P = synth.params_for(cfg)
+    cases.append((devplanes.resident_from_alignments(synth.generate_alignments(cfg, 300, P), engine0, P), P))
+    rng = np.random.default_rng(77)
+    ref = "".join(rng.choice(list("ACGT"), size=300))
+    open(str(tmp_path / "m.fa"), "w").write(">chrM\n" + ref + "\n")
+    recs = []
+    for i in range(16000):
+        start = 100 + int(rng.integers(0, 4)) if i % 9 else int(rng.integers(20, 150))
+        for mate in (0, 1):
+            pos = start + (0 if mate == 0 else int(rng.integers(0, 6)))
+            recs.append(dict(tid=0, pos=pos, qname="r%d:x:BC%04d:y" % (i, int(rng.integers(0, 900))), flag=(0x41 if mate == 0 else 0x91),
+                             mapq=60, cigar=[(0, 50)], seq=ref[pos:pos + 50], qual=[30] * 50, nm=0))
+    recs.sort(key=lambda r: r["pos"])
+    bam = str(tmp_path / "m.bam")
+    bamio.write_bam(bam, [("chrM", 300)], recs)
+    bamio.write_bai(bam)
+    fa = fasta.FastaFile(str(tmp_path / "m.fa"))
+    P2 = VcParams(mtDepth=100000, rpb=2.0, hpLen=8)
+    loci = [("chrM", str(p)) for p in range(40, 190)]
+    for _, rb in devplanes.iter_resident_batches(bam, fa, loci, P2, engine0, max_reads=64_000_000):
+        assert int(rb.loci["n_reads"].max()) > 24576 and int(rb.loci["n_reads"].min()) < 4096
+        cases.append((rb, P2))
+    for rb, prm in cases:
+        d_loci = devplanes.DevLoci(engine0, rb.loci)
+        p_host, p_dev = engine0.make_plan(rb.loci), engine0.make_plan_dev(d_loci, rb.n_loci)
+        r_host = p_host.run_devbuf(rb.planes, prm).copy()
+        r_dev = p_dev.run_devbuf(rb.planes, prm).copy()
+        p_host.close(); p_dev.close(); d_loci.free()
+        assert r_host.tobytes() == r_dev.tobytes()
