@@ -7,7 +7,8 @@ scaling: rank r calls loci [r*200k, (r+1)*200k) of the same seeded config), inpu
 before the timed region.  A step = one pass of the hot path (k_call_v2 bins + k_filter_loci) over
 the rank's batch, followed, for N > 1, by the gather of the rows to rank 0 (RCCL; the gather of a step
 overlaps the next step's kernels, two row buffers per rank - every step's rows are gathered inside the
-timed region).
+timed region).  `--scaling strong --config C4`: BASELINE's configs[3], 1 M loci IN TOTAL sharded over
+the ranks (it fits one MI355X as well: the N = 1 anchor of that curve).
 
 The timed region is a block of EXACTLY --steps steps between barrier + synchronize on both sides; the
 block is repeated --blocks times (default 5) and `value` / `ms_per_step` come from the MEDIAN block
@@ -15,12 +16,17 @@ block is repeated --blocks times (default 5) and `value` / `ms_per_step` come fr
 to a percent.
 
 Prints ONE JSON line on rank 0 (see the task contract): value = loci of all ranks / max-over-ranks
-time; roofline = algorithmic bytes (16 B/read + 360 B/locus) of the dominant kernel
-over its mean HIP-event duration, against 8 TB/s, next to the bytes the kernel actually has to move
-(`needed_bytes_per_launch`, `frac_needed`); cpu_baseline = CPU legs timed on a bounded sample of the
-same workload (rank 0, N = 1 only); parity = EVERY row of the run against the CPU restatement with the
-number of loci whose order-dependent fields were excused; other_configs = the other single-GPU
-BASELINE configs (C2, C5), each timed the same way in the same process.
+time; roofline = the bytes the dominant kernel has to move per launch over its mean HIP-event duration,
+against 8 TB/s (`frac`, with `frac_basis`; SURVEY.md 8d's 16 B/read figure beside it as
+`frac_survey_8d`); cpu_baseline = CPU legs timed on a bounded sample of the same workload (rank 0,
+N = 1 only; physical cores stated, the single-process rate beside the pool's); parity = EVERY row of the
+run against the CPU restatement with the number of loci whose order-dependent fields were excused, the
+loci that reached filterVariants, the Fisher tests run and the largest p-value difference;
+other_configs = the other single-GPU shapes (C2, C5, X3 - 30 % of the loci with a candidate -, EX - the
+statistics of the reference's own example run), each timed the same way in the same process;
+from_alignments = the same C3 depth shape timed from where the reference's hot loop starts
+(smCounter.py:316): alignments resident in HBM -> plane builder -> launch plan -> hot path
+(smcounter_amd/fa_leg.py), with the plane-writing kernel's own roofline.
 """
 from __future__ import annotations
 
@@ -88,13 +94,15 @@ class Resident(object):
         import numpy as np
         from smcounter_amd import abi
         got = self.plan.download(rows)
-        tot = {"loci": 0, "mismatches": 0, "fragile_skipped": 0, "near_tie_skipped": 0, "pi_max_abs_diff": 0.0, "detail": []}
+        tot = {"loci": 0, "mismatches": 0, "fragile_skipped": 0, "near_tie_skipped": 0, "pi_max_abs_diff": 0.0, "loci_filtered": 0,
+               "fisher_tests_run": 0, "p_max_abs_diff": 0.0, "detail": []}
         lo = 0
         for want, fragile, pi_all in self.want:
             rep = abi.parity_report(got[lo:lo + len(want)], want, fragile, pi_all)
-            for k in ("loci", "mismatches", "fragile_skipped", "near_tie_skipped"):
+            for k in ("loci", "mismatches", "fragile_skipped", "near_tie_skipped", "loci_filtered", "fisher_tests_run"):
                 tot[k] += rep[k]
-            tot["pi_max_abs_diff"] = max(tot["pi_max_abs_diff"], rep["pi_max_abs_diff"])
+            for k in ("pi_max_abs_diff", "p_max_abs_diff"):
+                tot[k] = max(tot[k], rep[k])
             tot["detail"] += rep["detail"]
             lo += len(want)
         tot["detail"] = tot["detail"][:3]
@@ -107,9 +115,14 @@ class Resident(object):
 
 
 def roofline_block(plan_loci, k_ms, k_n, k_loci, k_reads, cfg_key):
+    """`achieved` / `frac`: the bytes the dominant kernel HAS to move per launch (the two planes it reads - 8 B per read slot -,
+    umi_start, descriptors, rows) over its mean HIP-event duration, against the 8 TB/s peak.  SURVEY.md 8d's algorithmic figure
+    (16 B per read + 360 B per locus: the four planes of the layout, of which the kernels read two - the plane builder digests
+    the other two into the read class) is kept beside it as achieved_survey_8d / frac_survey_8d; it can exceed what a copy
+    achieves on this part and is not a fraction of anything the kernel does."""
     alg_bytes = 16.0 * k_reads + 360.0 * k_loci              # per launch of the dominant kernel (SURVEY 8d)
-    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     need = needed_bytes(plan_loci)
+    achieved = need / (k_ms * 1e-3) / 1e9
     # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), expressed like `achieved`:
     # GB/s over THIS run's measured kernel duration.  A constant read from the committed profile, not measured here.
     traffic, traffic_bytes, src = None, None, None
@@ -121,13 +134,34 @@ def roofline_block(plan_loci, k_ms, k_n, k_loci, k_reads, cfg_key):
             traffic = traffic_bytes / (k_ms * 1e-3) / 1e9
             src = "profiles/traffic.json <- " + rec.get("source", "rocprofv3 --pmc")
     return {"bound": "hbm", "kernel": "k_call_v2", "achieved": achieved, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "frac_basis": "needed bytes per launch (8 B per read slot + umi_start + descriptor + row) / kernel time / 8 TB/s",
+            "traffic": traffic, "traffic_source": src,
             "kernel_ms": k_ms, "kernel_samples": k_n, "loci_per_launch": k_loci,
-            "alg_bytes_per_launch": alg_bytes, "needed_bytes_per_launch": need,
-            "achieved_needed": need / (k_ms * 1e-3) / 1e9, "frac_needed": need / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "hbm_bytes_per_launch_pmc": traffic_bytes,
-            "note": "frac = SURVEY 8d's 16 B/read; the kernels load 8 B/read (meta + frag planes), so frac_needed is the "
-                    "fraction of the HBM peak actually required of the memory system"}
+            "needed_bytes_per_launch": need, "hbm_bytes_per_launch_pmc": traffic_bytes,
+            "alg_bytes_per_launch_survey_8d": alg_bytes, "achieved_survey_8d": alg_bytes / (k_ms * 1e-3) / 1e9,
+            "frac_survey_8d": alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "note": "frac_survey_8d counts SURVEY 8d's 16 B/read; the kernels load 8 B/read (meta + frag planes), the other 8 are "
+                    "consumed by the plane builder (the from_alignments leg times it)"}
+
+
+def physical_cores():
+    """Physical cores among the CPUs this process may run on (/proc/cpuinfo: distinct (physical id, core id))."""
+    try:
+        allowed = os.sched_getaffinity(0)
+        cores, cpu, phys, core = set(), None, None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("processor"):
+                cpu = int(line.split(":")[1]); phys = core = None
+            elif line.startswith("physical id"):
+                phys = int(line.split(":")[1])
+            elif line.startswith("core id"):
+                core = int(line.split(":")[1])
+                if cpu in allowed:
+                    cores.add((phys, core))
+        return len(cores) or len(allowed)
+    except Exception:
+        return os.cpu_count() or 1
 
 
 def main():
@@ -144,7 +178,11 @@ def main():
     ap.add_argument("--chunk", type=int, default=25000, help="loci generated/uploaded per chunk")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the every-row check against the CPU restatement")
-    ap.add_argument("--no-other-configs", action="store_true", help="skip the C2 / C5 one-liners")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the C2 / C5 / X3 / EX one-liners")
+    ap.add_argument("--no-from-alignments", action="store_true", help="skip the leg that starts from alignments (plane builder + hot path)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: the config's loci PER GPU (default, the driver's scaling run); strong: the config's loci in total, "
+                         "sharded over the ranks (e.g. --config C4: 1 M loci; fits one MI355X too)")
     ap.add_argument("--rows", choices=("gather", "resident"), default="gather",
                     help="N > 1: gather every step's rows to rank 0 (default; overlapped with the next step) or leave "
                          "them in each rank's HBM (diagnostic: isolates the collective)")
@@ -184,7 +222,9 @@ def main():
     cfg = synth.CONFIGS[a.config]
     params = synth.params_for(cfg)
     n_loc = a.loci_per_gpu or cfg.n_loci
-    lo, hi = smcdist.shard_range(n_loc * world, rank, world)      # contiguous, equal (weak scaling)
+    total_loci = n_loc * world if a.scaling == "weak" else n_loc
+    lo, hi = smcdist.shard_range(total_loci, rank, world)         # contiguous, equal shares of the ordered locus list
+    n_mine = hi - lo
     eng = engine.Engine(local_rank)
     dev = torch.device("cuda", local_rank)
     oracle = None
@@ -250,14 +290,13 @@ def main():
 
     out = None
     if rank == 0:
-        total_loci = n_loc * world
         out = {
             "metric": "loci/sec at fixed read-depth x rpb", "value": total_loci * a.steps / elapsed,
             "unit": "loci/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": a.scaling,
             "vs_baseline": None, "dtype": "u8/u32 scan + f64 posterior", "data": "synthetic",
-            "config": {"workload": "%s: %d loci/GPU x %d reads (%d UMIs x %d rpb), seed %d"
-                       % (cfg.name, n_loc, cfg.depth, cfg.n_umi, cfg.rpb, cfg.seed),
+            "config": {"workload": "%s: %d loci%s x %d reads (%d UMIs x %d rpb), seed %d"
+                       % (cfg.name, n_loc, "/GPU" if a.scaling == "weak" else " in total", cfg.depth, cfg.n_umi, cfg.rpb, cfg.seed),
                        "loci_total": total_loci,
                        "parallelism": "loci sharded x%d, %s" % (world, ("%s rows gathered to rank 0" % ("packed wire" if packed else "full"))
                                                                  if gather else ("single GPU" if world == 1 else
@@ -266,7 +305,7 @@ def main():
                                                                          "check of the N > 1 path, not a measurement"} if share_gpu else {})},
             "blocks": {"n": len(blocks), "steps_each": a.steps, "ms_per_step": [round(b / a.steps * 1e3, 4) for b in blocks],
                        "value_from": "median block", "spread_pct": round(100.0 * (max(blocks) - min(blocks)) / elapsed, 2)},
-            "roofline": roofline_block(res.loci, k_ms, k_n, k_loci, k_reads, "%s:%d" % (a.config, n_loc)),
+            "roofline": roofline_block(res.loci, k_ms, k_n, k_loci, k_reads, "%s:%d" % (a.config, n_mine)),
             "host_buffers": "inputs resident in HBM when the timed region starts; handing host buffers instead "
                             "(smc_call_batch_host: H2D of 8 B/read + kernels + D2H of the rows) measured 1.94 M loci/s on C3 "
                             "(DESIGN.md section 5) - PCIe-bound, never `value`",
@@ -274,6 +313,7 @@ def main():
         if cpu is not None:
             out["cpu_baseline"], out["cpu_baseline_c"] = cpu["python_pool"], cpu["c_port"]
             out["cpu_baseline_c_all_cores"] = cpu["c_port_all_cores"]
+            out["cpu_baseline_single_process"] = cpu["python_single"]
         if oracle is not None:
             res.run(rows)
             torch.cuda.synchronize()
@@ -282,9 +322,14 @@ def main():
     del rows, pipe
     if rank == 0 and world == 1 and not a.no_other_configs:
         out["other_configs"] = {}
-        for name in ("C2", "C5"):
+        for name in ("C2", "C5", "X3", "EX"):           # X3: 30 % of the loci reach the filters; EX: the example run's statistics
             if name != a.config:
                 out["other_configs"][name] = other_config(eng, name, a, dev, nthreads, oracle)
+        if not a.no_from_alignments:
+            from smcounter_amd import fa_leg
+            torch.cuda.empty_cache()
+            out["from_alignments"] = fa_leg.run_leg(eng, "C3", a.loci_per_gpu or synth.CONFIGS["C3"].n_loci, max(3, a.steps // 4),
+                                                    2, 3, nthreads, parity_loci=0 if a.no_parity else 512)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:
@@ -318,8 +363,8 @@ def other_config(eng, name, a, dev, nthreads, oracle):
     o = {"workload": "%s: %d loci x %d reads (%d UMIs x %d rpb), seed %d" % (name, cfg.n_loci, cfg.depth, cfg.n_umi, cfg.rpb, cfg.seed),
          "value": cfg.n_loci * a.steps / el, "unit": "loci/s", "ms_per_step": el / a.steps * 1e3,
          "blocks_ms_per_step": [round(b / a.steps * 1e3, 4) for b in blocks],
-         "roofline": {k: rf[k] for k in ("achieved", "frac", "achieved_needed", "frac_needed", "kernel_ms", "loci_per_launch",
-                                         "alg_bytes_per_launch", "needed_bytes_per_launch")}}
+         "roofline": {k: rf[k] for k in ("achieved", "frac", "frac_basis", "kernel_ms", "loci_per_launch", "needed_bytes_per_launch",
+                                         "achieved_survey_8d", "frac_survey_8d")}}
     if oracle is not None:
         res.run(rows)
         torch.cuda.synchronize()
@@ -352,21 +397,37 @@ def cpu_leg(a):
         mt_rows = oracle_lib.call_batch_mt(sample, abi.c_params(params), abi.ROW_DTYPE, cores)
     dt_cmt = (time.perf_counter() - t) / reps
     assert mt_rows.tobytes() == ref_rows.tobytes()
+    phys = physical_cores()
+    # one process, no pool: what one core does with the pure-Python restatement (no task pickling, no result pipes)
+    n_one = min(n, 120)
+    t = time.perf_counter()
+    vc_port.call_batch(sample, params, n_cpu=1, loci=range(n_one))
+    dt_one = time.perf_counter() - t
     n_py = min(n, max(2000, 40 * cores))
     pool = vc_port.make_pool(cores)                 # started and warmed outside the timed region
+    vc_port.call_config(a.config, params, range(cores), pool)          # (first import of the generator in every worker)
     t = time.perf_counter()
-    vc_port.call_batch(sample, params, n_cpu=cores, loci=range(n_py), pool=pool)
+    got = vc_port.call_config(a.config, params, range(n_py), pool)
     dt_py = time.perf_counter() - t
     pool.close()
     pool.join()
+    want = vc_port.call_batch(sample, params, n_cpu=1, loci=range(4))
+    assert [r["cvg"] for r in got[:4]] == [r["cvg"] for r in want] and [r["pi"] for r in got[:4]] == [r["pi"] for r in want]
+    per_core_pool = n_py / dt_py / phys
     return {
-        "python_pool": {"value": n_py / dt_py, "unit": "loci/s", "cores": cores, "kind": "port",
+        "python_pool": {"value": n_py / dt_py, "unit": "loci/s", "cores": phys, "logical_cpus": cores, "kind": "port",
+                        "per_physical_core": per_core_pool,
                         "sample": "first %d loci of the same workload, pure-Python port oracle/vc_port.py under "
-                                  "multiprocessing.Pool(%d), one task per locus, %.1f s (pool already started)"
+                                  "multiprocessing.Pool(%d), one task per locus as smCounter.py:683-685, every worker making its own "
+                                  "locus's input (the reference's worker reads its own BAM region), %.1f s (pool already started)"
                                   % (n_py, cores, dt_py)},
+        "python_single": {"value": n_one / dt_one, "unit": "loci/s", "cores": 1, "kind": "port",
+                          "sample": "first %d loci, oracle/vc_port.py in this process (no pool), %.1f s; SURVEY.md section 6 timed the "
+                                    "imported reference at ~51 loci/s on one core of the build container for this shape"
+                                    % (n_one, dt_one)},
         "c_port": {"value": n / dt_c, "unit": "loci/s", "cores": 1, "kind": "port",
                    "sample": "first %d loci, C restatement oracle/smc_oracle.c, 1 thread, %.1f s" % (n, dt_c)},
-        "c_port_all_cores": {"value": n / dt_cmt, "unit": "loci/s", "cores": cores, "kind": "port",
+        "c_port_all_cores": {"value": n / dt_cmt, "unit": "loci/s", "cores": phys, "logical_cpus": cores, "kind": "port",
                              "sample": "first %d loci, C restatement oracle/smc_oracle.c on %d threads (contiguous locus "
                                        "ranges), mean of %d passes, %.3f s each" % (n, cores, reps, dt_cmt)}}
 

@@ -215,6 +215,33 @@ def _task(args):
     return vc_locus(*args)
 
 
+def _task_own_input(args):
+    """One locus whose input the WORKER makes itself - as the reference's worker opens the BAM and piles up its own locus
+    (smCounter.py:275, :316): the parent sends a config name and a locus index, not the reads."""
+    cfg_name, l, prm = args
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from smcounter_amd import synth
+    from smcounter_amd.params import VcParams
+    P = VcParams(**prm)
+    db = synth.generate_native(synth.CONFIGS[cfg_name], l, l + 1, P, nthreads=1)
+    L = db.loci[0]
+    n = int(L["n_reads"])
+    return vc_locus(db.meta[:n], db.umi[:n], db.frag[:n] & 0x07FFFFFF, db.dist[:n], int(L["ref_allele"]), int(L["n_alleles"]),
+                    int(L["snp_mask"]), P.minBQ, P.minMQ, P.mtDrop, P.primerDist, P.ds, P.smt, None)
+
+
+def call_config(cfg_name, params, loci, pool):
+    """The port over loci of a synthetic config, one task per locus, every worker generating its own locus."""
+    prm = dict(minBQ=params.minBQ, minMQ=params.minMQ, mtDepth=params.mtDepth, rpb=params.rpb, hpLen=params.hpLen,
+               mismatchThr=params.mismatchThr, mtDrop=params.mtDrop, maxMT=params.maxMT, primerDist=params.primerDist)
+    results = [pool.apply_async(_task_own_input, ((cfg_name, int(l), prm),)) for l in loci]
+    return [r.get() for r in results]
+
+
 def _noop(x):
     return x
 

@@ -224,7 +224,18 @@ def parity_report(a: np.ndarray, b: np.ndarray, fragile=None, pi_all=None, pi_to
     bad = compare_rows(a, b, pi_tol, p_tol, fragile, pi_all)
     ok = ((a["status"] & 0xff) == ST_OK) & ((b["status"] & 0xff) == ST_OK)
     d = np.abs(a["pi"] - b["pi"])[ok]
+    # the p-value half of the metric: how many loci reached filterVariants, how many Fisher tests ran there (a p-value that is
+    # not NaN in the CPU restatement's row), and the largest difference between the two implementations' p-values
+    p_max, n_tests = 0.0, 0
+    for f in ("p_sb", "p_r1", "p_r2", "p_pr"):
+        x, y = a["cand"][f], b["cand"][f]
+        both = ~np.isnan(x) & ~np.isnan(y)
+        n_tests += int((~np.isnan(y)).sum())
+        if both.any():
+            p_max = max(p_max, float(np.abs(x[both] - y[both]).max()))
     return {"loci": int(len(a)), "mismatches": len(bad),
             "fragile_skipped": 0 if fragile is None else int((np.asarray(fragile) > 0).sum()),
             "near_tie_skipped": len(near_tie_loci(a, b, pi_all=pi_all)),
-            "pi_max_abs_diff": float(d.max()) if d.size else 0.0, "detail": bad[:3]}
+            "pi_max_abs_diff": float(d.max()) if d.size else 0.0,
+            "loci_filtered": int((b["cand"]["flt_applied"] != 0).any(axis=1).sum()),
+            "fisher_tests_run": n_tests, "p_max_abs_diff": p_max, "detail": bad[:3]}

@@ -102,6 +102,10 @@ CONFIGS = {
     "X10": SynthConfig("X10", 300, 20000, 9, 20170429),       # 180 k reads per locus
     # C3's shape with a 10 % variant at 30 % of the loci: a third of the rows goes through k_filter_loci
     "X3": SynthConfig("X3", 40_000, 50, 60, 20170422, alt_locus_frac=0.3, alt_af=0.1),
+    # the statistics of the reference's own example run (2000 loci, mean 58 k reads and 4,162 barcodes per
+    # locus, 13.9 reads per barcode, 602 of 2000 loci reaching filterVariants): 4162 barcodes x 14 reads, a variant at 30 % of
+    # the loci
+    "EX": SynthConfig("EX", 2_000, 4162, 14, 20170430, alt_locus_frac=0.3, alt_af=0.1),
 }
 
 
