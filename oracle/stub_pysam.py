@@ -75,8 +75,12 @@ def _make_read(r):
     a.is_read2 = r["is_read2"]
     a.is_reverse = r["is_reverse"]
     a.query_alignment_length = r["qalen"]
-    a.query_sequence = _Seq(r["qpos"], r["site"], r["ins"])
-    a.query_qualities = _Quals(r["qpos"], r["bq"])
+    if "seq" in r:                     # a real record (tests/golden/make_bam_golden.py): the whole sequence and qualities
+        a.query_sequence = r["seq"]
+        a.query_qualities = r["quals"]
+    else:
+        a.query_sequence = _Seq(r["qpos"], r["site"], r["ins"])
+        a.query_qualities = _Quals(r["qpos"], r["bq"])
     p = _PileupRead()
     p.alignment = a
     p.indel = r["indel"]
