@@ -116,6 +116,33 @@ def call_shard(args, params: VcParams, loci, device: int, early=None):
     return output.done()
 
 
+def call_shard_rows(args, params: VcParams, loci, device: int):
+    """A rank's share as NUMBERS: (rows abi.ROW_DTYPE[n], reference letters, allele tables) - the distributed command line
+    sends these to rank 0 (packed: dist.pack_shard) which prints every row; no strings are made on the other ranks."""
+    import numpy as np
+    from . import abi, devplanes
+    from .engine import Engine
+    if not len(loci):
+        return np.zeros(0, abi.ROW_DTYPE), [], []
+    ref = fasta.FastaFile(args.refGenome)
+    eng = Engine(device)
+    per_node = int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE", "1"))
+    nthreads = max(1, len(os.sched_getaffinity(0)) // max(1, per_node))
+    parts, refs, tables = [], [], []
+    try:
+        if os.environ.get("SMC_PLANES", "device") == "host":
+            for _, db in bamio.iter_device_batches_native(args.bamFile, ref, loci, params, max_reads=args.batchReads, nthreads=nthreads):
+                parts.append(eng.call_batch_host(db, params)); refs += list(db.ref); tables += list(db.alleles)
+        else:
+            batches = devplanes.iter_resident_batches(args.bamFile, ref, loci, params, eng, max_reads=8 * args.batchReads,
+                                                      nthreads=nthreads, all_planes=False)
+            for _, rb in _prefetch(batches, depth=1):
+                parts.append(vc.vc_resident_rows(rb, params, eng)); refs += list(rb.ref); tables += list(rb.alleles)
+    finally:
+        eng.close()
+    return (np.concatenate(parts) if parts else np.zeros(0, abi.ROW_DTYPE)), refs, tables
+
+
 class _Rows(list):
     """The shard's row strings; keeps the native printer's per-row int(PI) (rows.RowLines.pred) alongside when every batch
     came with one, for the post-filter and the writers."""
@@ -222,23 +249,41 @@ def _main(args) -> int:
         # A failing locus (or a decoder error) on one rank must not leave the others waiting in the collective
         # until the RCCL timeout: every rank first agrees on a status, then all raise together or all gather.
         import torch.distributed as tdist
-        err, output = None, []
+        import numpy as np
+        import torch
+        from . import abi
+        err, payload = None, None
         try:
-            output = call_shard(args, params, loc_list[lo:hi], local_rank)
-            vc.raise_on_exception(output, loc_list[lo:hi])
+            r_rows, r_ref, r_tab = call_shard_rows(args, params, loc_list[lo:hi], local_rank)
+            if len(r_rows) != hi - lo:
+                raise RuntimeError("%d rows for %d loci" % (len(r_rows), hi - lo))
+            payload = smcdist.pack_shard(abi.pack_wire(r_rows), r_ref, r_tab)
         except Exception as e:                       # reported by every rank below
             err = "rank %d: %s: %s" % (rank, type(e).__name__, e)
         try:
             failed = [m for m in smcdist.all_gather_status(err) if m]
             if failed:
                 raise RuntimeError("smCounter failed on %d of %d ranks: %s" % (len(failed), world, " | ".join(failed)))
-            output = smcdist.gather_strings(output, dst=0)
+            # ONE gather of byte blocks: 168-byte wire rows + the rank's allele-string table; a rank whose
+            # share is empty sends an empty table
+            t = torch.from_numpy(payload)
+            if tdist.get_backend() == "nccl":
+                t = t.to(torch.device("cuda", local_rank))
+            blocks = smcdist.gatherv_bytes(t, dst=0)
             tdist.barrier()
         finally:
             if tdist.is_initialized():
                 tdist.destroy_process_group()
         if rank != 0:
             return writers.pi_threshold(args.mtDepth, args.threshold)
+        wires, refs, tabs = [], [], []
+        for b in blocks:
+            w, rf, tb = smcdist.unpack_shard(b.cpu().numpy())
+            wires.append(w); refs += rf; tabs += tb
+        all_rows = abi.unpack_wire(np.concatenate(wires)) if wires else np.zeros(0, abi.ROW_DTYPE)
+        view = vc.LocusView([c for c, _ in loc_list], [int(p) for _, p in loc_list], refs, tabs)
+        output = vc._strings(all_rows, view, params, fasta.FastaFile(args.refGenome))
+        vc.raise_on_exception(output, loc_list)
 
     print("begin variant filtering and output")
     have_rep = [b for b in (args.bedTandemRepeats, args.bedRepeatMaskerSubset) if b and os.path.exists(b)]

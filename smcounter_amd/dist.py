@@ -61,8 +61,8 @@ def gatherv_rows(rows, counts: Sequence[int], row_bytes: int, dst: int = 0):
 
 
 def gather_strings(local: Sequence[str], dst: int = 0):
-    """Row strings of every rank, concatenated in rank order on `dst` (None elsewhere): the distributed
-    command line's hand-over of its 45-field rows (indel alleles make them variable-length) to the writers."""
+    """Row strings of every rank, concatenated in rank order on `dst` (None elsewhere).  (Round 2's hand-over of the command
+    line - pickled strings; the command line now gathers packed wire rows + an allele table: pack_shard / gatherv_bytes.)"""
     import torch.distributed as dist
     world, rank = dist.get_world_size(), dist.get_rank()
     parts = [None] * world if rank == dst else None
@@ -70,6 +70,64 @@ def gather_strings(local: Sequence[str], dst: int = 0):
     if rank != dst:
         return None
     return [s for part in parts for s in part]
+
+
+def pack_shard(wire: np.ndarray, ref: Sequence[str], alleles: Sequence[Sequence[str]]) -> np.ndarray:
+    """One rank's hand-over to the writing rank as ONE byte block: the packed wire rows (abi.WIRE_DTYPE, 168 B per locus: every
+    printed number), the reference letters, and the rank's allele-string table - only the keys beyond the six fixed ones
+    (indel alleles; SURVEY.md 8e: variable-length strings travel as a per-rank table beside the fixed-width rows).
+    Layout: int64 n_rows, int64 blob_bytes | wire rows | JSON blob [ref letters, {locus: [extra keys]}]."""
+    import json
+    wire = np.ascontiguousarray(wire)
+    n = len(wire)
+    assert len(ref) == n and len(alleles) == n
+    one = all(len(r) == 1 for r in ref)
+    extras = {str(i): list(t[6:]) for i, t in enumerate(alleles) if len(t) > 6}
+    blob = json.dumps(["".join(ref) if one else list(ref), extras]).encode()
+    head = np.array([n, len(blob)], np.int64)
+    return np.concatenate([head.view(np.uint8), wire.view(np.uint8).reshape(-1), np.frombuffer(blob, np.uint8)])
+
+
+def unpack_shard(block: np.ndarray):
+    """-> (wire rows, ref letters, allele tables) of pack_shard."""
+    import json
+    from .abi import WIRE_DTYPE
+    from .pileup import BASE_ALLELES
+    block = np.ascontiguousarray(block, np.uint8)
+    n, nb = (int(x) for x in block[:16].view(np.int64))
+    w_end = 16 + n * WIRE_DTYPE.itemsize
+    wire = block[16:w_end].view(WIRE_DTYPE)
+    ref, extras = json.loads(bytes(block[w_end:w_end + nb]).decode())
+    ref = list(ref)
+    base = list(BASE_ALLELES)
+    alleles = [base] * n
+    for k, t in extras.items():
+        alleles[int(k)] = base + list(t)
+    return wire, ref, alleles
+
+
+def gatherv_bytes(payload, dst: int = 0):
+    """Byte blocks of different sizes from every rank to `dst` (a list of uint8 tensors in rank order there, None elsewhere):
+    sizes first (one small all_gather), then ONE gather of blocks padded to the largest (RCCL has no gatherv).  `payload`: a
+    uint8 tensor on the device the backend moves (CPU for gloo, the rank's GPU for nccl)."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    size = torch.tensor([payload.numel()], dtype=torch.int64, device=payload.device)
+    sizes = [torch.zeros_like(size) for _ in range(world)]
+    dist.all_gather(sizes, size)
+    sizes = [int(t.item()) for t in sizes]
+    mx = max(sizes)
+    buf = payload
+    if payload.numel() < mx:
+        buf = torch.zeros(mx, dtype=torch.uint8, device=payload.device)
+        buf[:payload.numel()] = payload
+    glist = [torch.empty(mx, dtype=torch.uint8, device=payload.device) for _ in range(world)] if rank == dst else None
+    if mx:
+        dist.gather(buf, glist, dst=dst)
+    if rank != dst:
+        return None
+    return [g[:sizes[r]] for r, g in enumerate(glist)]
 
 
 def all_gather_status(err: Optional[str]) -> List[Optional[str]]:

@@ -62,6 +62,28 @@ def vc_resident(rb, params: VcParams, refprov, eng: _engine.Engine) -> List[str]
     return _strings(out_rows, rb, params, refprov)
 
 
+def vc_resident_rows(rb, params: VcParams, eng: _engine.Engine):
+    """The numeric rows (abi.ROW_DTYPE, a copy) of a resident batch - what a rank of the distributed command line hands to the
+    writing rank (packed) instead of strings."""
+    plan = eng.make_plan(rb.loci)
+    try:
+        return plan.run_devbuf(rb.planes, params).copy()
+    finally:
+        plan.close()
+
+
+class LocusView(object):
+    """What rows.format_rows needs of a batch besides the rows: chrom / pos / ref / allele tables per locus."""
+
+    def __init__(self, chrom, pos, ref, alleles):
+        import numpy as np
+        self.chrom, self.pos, self.ref, self.alleles = list(chrom), np.asarray(pos, np.int64), list(ref), list(alleles)
+
+    @property
+    def n_loci(self):
+        return len(self.chrom)
+
+
 def raise_on_exception(output: List[str], loc_list) -> None:
     """main()'s scan for worker failures (smCounter.py:689-694)."""
     pred = getattr(output, "pred", None)

@@ -124,31 +124,93 @@ def test_two_rank_gather_of_packed_wire_rows_prints_the_same_strings():
     assert got["cand"]["pi"].tobytes() == full["cand"]["pi"].tobytes()
 
 
-def _cli_worker(rank, world, port, tmp, q):
+def _cli_worker(rank, world, port, tmp, q, weights=None):
     """One rank of the distributed command line; the GPU call is swapped for the CPU restatement (this test is
-    about sharding, the string gather and the writers on rank 0)."""
+    about sharding, the gather of packed wire rows + allele tables, and printing + the writers on rank 0).  `weights`:
+    locus weights that replace the BAI-derived ones (to force uneven and EMPTY shares)."""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
                       WORLD_SIZE=str(world), SMC_DIST_BACKEND="gloo")
-    from smcounter_amd import abi, bamio, cli, fasta, rows
+    from smcounter_amd import abi, bamio, cli, fasta
     import oracle_lib
 
-    def cpu_call_shard(args, params, loci, device, early=None):
+    def cpu_call_shard_rows(args, params, loci, device):
+        if not len(loci):
+            return np.zeros(0, abi.ROW_DTYPE), [], []
         ref = fasta.FastaFile(args.refGenome)
-        out = []
+        parts, refs, tabs = [], [], []
         for _, db in bamio.iter_device_batches_native(args.bamFile, ref, loci, params, max_reads=args.batchReads):
-            R = oracle_lib.call_batch(db, abi.c_params(params), abi.ROW_DTYPE)
-            out.extend(rows.format_rows(R, db, params, ref))
-        return out
-    cli.call_shard = cpu_call_shard
+            parts.append(oracle_lib.call_batch(db, abi.c_params(params), abi.ROW_DTYPE)); refs += list(db.ref); tabs += list(db.alleles)
+        return np.concatenate(parts), refs, tabs
+    cli.call_shard_rows = cpu_call_shard_rows
+    if weights is not None:
+        bamio.locus_weights = lambda path, loci: np.asarray(weights(len(loci)), np.float64)
     prefix = os.path.join(tmp, "dist")
     thr = cli.main(dict(outPrefix=prefix, bamFile=os.path.join(tmp, "case.bam"), bedTarget=os.path.join(tmp, "case.bed"),
                         mtDepth=12, rpb=3.0, hpLen=8, refGenome=os.path.join(tmp, "case.fa"), threshold=10,
                         batchReads=300))
     if rank == 0:
         q.put(thr)
+
+
+def _skewed_weights(n):
+    """All the weight on the first locus and the last third: of four ranks, two get NOTHING and the others unequal shares."""
+    w = [0.0] * n
+    w[0] = 100.0
+    for i in range(2 * n // 3, n):
+        w[i] = 1.0
+    return w
+
+
+def _single_process_expectation(tmp_path):
+    import bam_fixture  # noqa: F401
+    from smcounter_amd import abi, bamio, bedops, fasta, postfilter, rows
+    from smcounter_amd.params import VcParams
+    import oracle_lib
+    P = VcParams(mtDepth=12, rpb=3.0, hpLen=8)
+    fa = fasta.FastaFile(str(tmp_path / "case.fa"))
+    loci = bedops.expand_loci(str(tmp_path / "case.bed"))
+    want = []
+    for _, db in bamio.iter_device_batches_native(str(tmp_path / "case.bam"), fa, loci, P):
+        want.extend(rows.format_rows(oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE), db, P, fa))
+    return postfilter.apply_repeat_filters(want, {}, {}), loci
+
+
+@pytest.mark.timeout(300)
+def test_four_ranks_uneven_shares_and_empty_ranks_write_the_single_process_files(tmp_path):
+    """Four ranks, shares forced to (1 locus, none, none, the rest): the ranks without loci take part in the status agreement
+    and the gather with an empty block; rank 0 prints every row from the packed wire rows + allele tables - the same all.txt
+    as one process (the fixture has indel alleles: the tables matter)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bam_fixture
+    from smcounter_amd import dist
+    case = bam_fixture.make_case(str(tmp_path))
+    for k, name in (("bam", "case.bam"), ("bed", "case.bed"), ("fasta", "case.fa")):
+        os.replace(case[k], str(tmp_path / name))
+    if os.path.exists(case["fasta"] + ".fai"):
+        os.replace(case["fasta"] + ".fai", str(tmp_path / "case.fa.fai"))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cli_worker, args=(r, 4, port, str(tmp_path), q, _skewed_weights)) for r in range(4)]
+    for p in procs:
+        p.start()
+    assert q.get(timeout=240) == 10
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want, loci = _single_process_expectation(tmp_path)
+    cuts = dist.shard_by_reads(_skewed_weights(len(loci)), 4)
+    assert cuts[1] == cuts[2] == cuts[3] and 0 < cuts[1] < len(loci)          # two ranks without a locus
+    got = open(str(tmp_path / "dist.smCounter.all.txt")).read().split("\n")[1:-1]
+    assert got == want and len(got) == len(loci)
+    assert any("INS|" in r or "DEL|" in r or len(r.split("\t")[2]) > 1 or len(r.split("\t")[3]) > 1 for r in got)
 
 
 @pytest.mark.timeout(300)
@@ -200,8 +262,9 @@ def _failing_cli_worker(rank, world, port, tmp, q):
     def shard(args, params, loci, device):
         if rank == 1:
             raise ValueError("decoder broke on purpose")
-        return ["row"] * len(loci)
-    cli.call_shard = shard
+        from smcounter_amd import abi
+        return np.zeros(len(loci), abi.ROW_DTYPE), ["A"] * len(loci), [list("ATGCN") + ["DEL"]] * len(loci)
+    cli.call_shard_rows = shard
     try:
         cli.main(dict(outPrefix=os.path.join(tmp, "fail"), bamFile=os.path.join(tmp, "case.bam"),
                       bedTarget=os.path.join(tmp, "case.bed"), mtDepth=12, rpb=3.0, hpLen=8,
