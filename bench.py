@@ -105,6 +105,8 @@ class Resident(object):
                 tot[k] = max(tot[k], rep[k])
             tot["detail"] += rep["detail"]
             lo += len(want)
+        from smcounter_amd import rows as _rows
+        tot["pi_boundary_loci"] = int(len(_rows.pi_boundary_loci(got)))      # PI within 1e-8 of a printing / gating boundary
         tot["detail"] = tot["detail"][:3]
         tot["checked_against"] = "oracle/smc_oracle.c on all host cores, every locus of the run"
         return tot

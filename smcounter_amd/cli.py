@@ -108,6 +108,7 @@ def call_shard(args, params: VcParams, loci, device: int, early=None):
             batches = _prefetch(batches, depth=1)
         for first, rb in batches:
             output.add(vc.vc_resident(rb, params, ref, eng))
+            _report_boundary(eng.last_rows, rb.chrom, rb.pos)
         eng.close()
         return output.done()
     for first, pb in _prefetch(batches):
@@ -141,6 +142,17 @@ def call_shard_rows(args, params: VcParams, loci, device: int):
     finally:
         eng.close()
     return (np.concatenate(parts) if parts else np.zeros(0, abi.ROW_DTYPE)), refs, tables
+
+
+def _report_boundary(out_rows, chrom, pos):
+    """Log the loci whose PI lies within 1e-8 of a printing / gating boundary (rows.pi_boundary_loci): their text may differ
+    from the reference's in the last printed digit or in the FILTER gate although the numbers agree to ~ 3e-9."""
+    if out_rows is None:
+        return
+    from . import rows as _rows
+    idx = _rows.pi_boundary_loci(out_rows)
+    for l in idx.tolist():
+        print("note: prediction index of %s:%d lies within 1e-8 of a printing boundary" % (chrom[l], int(pos[l])))
 
 
 class _Rows(list):
@@ -283,6 +295,7 @@ def _main(args) -> int:
         all_rows = abi.unpack_wire(np.concatenate(wires)) if wires else np.zeros(0, abi.ROW_DTYPE)
         view = vc.LocusView([c for c, _ in loc_list], [int(p) for _, p in loc_list], refs, tabs)
         output = vc._strings(all_rows, view, params, fasta.FastaFile(args.refGenome))
+        _report_boundary(all_rows, view.chrom, view.pos)
         vc.raise_on_exception(output, loc_list)
 
     print("begin variant filtering and output")

@@ -1,27 +1,31 @@
 // smcounter_hip.hip - MI355X (gfx950) kernels and C ABI for smCounter's per-locus hot path.
 //
-// One workgroup per locus.  The whole of vc() up to (not including) string formatting runs on
-// the device (reference: /root/reference/smCounter.py):
-//   scan     per-read inclusion test + per-allele tallies            smCounter.py:368-460
-//   group    barcode -> fragment table in LDS, mate merge             :462-479
-//   score    calProb per barcode, PI / consensus accumulation         :26-98, :506-532
-//   rank     top-2 alleles, candidate(s), bi-allelic pre-condition    :534-555
-//   filter   filterVariants minus the two FASTA-dependent flags       :182-269  (second kernel)
+// The whole of vc() up to (not including) string formatting runs on the device (reference:
+// /root/reference/smCounter.py); one translation unit, the kernels in the .inc files below:
 //
-// Data layout (see include/smcounter_hip.h, smcounter_amd/features.py): four uint32 planes, 16 B
-// per pileup read, reads of a locus contiguous and 16-byte aligned; barcode ids dense per locus,
-// fragment ids dense per barcode, so the on-chip tables are directly indexed (no hashing).
+//   k_build_planes.inc   the planes of a run from its alignments (smCounter.py:316-366, :371-452, :462-471): the alignments of a
+//                        tile of 64 loci are radix-sorted ONCE by (barcode, fragment, file index); a wavefront (lane = locus)
+//                        then walks its part of that list - alignment record and CIGAR wave-uniform, the lane tests its own
+//                        position - first counting, then writing the plane words through an LDS staging buffer.
+//   k_plan.inc           the launch plan of a batch whose descriptors are in HBM: class and weight bucket per locus, the launch
+//                        lists written on the device (smc_plan_create_dev).
+//   k_call_v2.inc        scan + group + score + rank, one workgroup per locus (several for a deep one).  The reads arrive
+//                        barcode-major with dense ascending fragment slots and a 5-bit read class, so nothing is looked up:
+//                        the scan evaluates its predicates four reads at a time as byte lanes of one register (v_perm_b32,
+//                        DPP look-back), leaves ONE flag byte per read in LDS (fragment survives in bcDict / shows the reference
+//                        allele / merged pair / included / fragment start, :468-479), and counts alleleCnt (:379,401,459).
+//                        A barcode pass turns popcounts over the flag bytes into fragment counts; one-allele barcodes are
+//                        scored from a per-count table, the others by the 8-lane general calProb path (:26-98) with
+//                        lane-parallel FP64 epilogue; per-allele PI is summed in 64-bit fixed point (order-independent);
+//                        the E stage ranks (:534-555), and only for loci whose candidate reaches filterVariants are the eight
+//                        filter-only tallies counted, in one more pass over the just-streamed reads.
+//   k_filter_loci.inc    filterVariants minus the two FASTA-dependent flags (:182-269) for the loci on the worklist; Fisher
+//                        exact two-sided by chunked hypergeometric sums with a log-factorial table.
+//   k_pack_rows.inc      432-byte rows -> 168-byte wire rows for the multi-GPU gather.
 //
-// On-chip tables per locus (dynamic LDS, or a global scratch slab for loci that do not fit):
-//   umi_base[nU+1]  first fragment slot of each barcode (slot of its first read, from umi_start)
-//   frag word[nF]   one 32-bit word per fragment: (allele, quality) of its first and of its second
-//                   included read, in pileup order - which is memory order, a fragment's reads being
-//                   adjacent in the barcode-major batch: a read is "second" when the read just before it
-//                   has the same slot and is included (smCounter.py:468-479 depends on that order).
-//                   Written with one LDS atomicOr per included read; slots with >= 3 reads are flagged
-//                   and replayed sequentially.  The merge then overwrites it with the fragment's state.
-//   worklist[nU], umi_flag[nU], chunk masks (2 x u64 per 64 slots): see the U phase.
-// This is integer/branchy, HBM-streaming work: no MFMA.
+// Data layout (include/smcounter_hip.h): 16 B per pileup read in four uint32 planes, of which the locus
+// kernels read two (meta, frag) and umi_start; a 32-byte descriptor per locus; a 432-byte row out.
+// This is integer / branchy, HBM-streaming work: no MFMA.
 #include <hip/hip_runtime.h>
 
 #include <limits.h>

@@ -91,6 +91,7 @@ class Engine(object):
         self.ctx = h
         self._spare = {}                      # size class -> freed DevBuf pointers, reused before allocating anew
         self._pinned = {}                     # name -> (pointer, bytes) of page-locked staging memory
+        self.last_rows = None                 # rows of the last vc.vc_resident call (pinned staging: valid until the next)
 
     def pinned(self, name: str, dtype, count: int) -> np.ndarray:
         """A numpy array over page-locked host memory owned by the engine, one per `name`, grown when needed: staging for the

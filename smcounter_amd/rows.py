@@ -293,3 +293,21 @@ def _format_simple_rows(out, idx, simple, rows, db, params, refprov, cols, c_all
              str(vsm[0]), str(vsm[1]), str(vsm[2]), str(vsm[3]),
              ff(rnd(pi[0], 2)), ff(rnd(pi[1], 2)), ff(rnd(pi[2], 2)), ff(rnd(pi[3], 2)), ";"]
         out[l] = "\t".join(f)
+
+
+def pi_boundary_loci(rows, eps: float = 1e-8):
+    """Loci whose printed text could differ from the reference's although every number agrees to the tolerance: a prediction
+    index the row prints (PI_A..PI_C, the candidates' PI: smCounter.py:591-593) within `eps` of a half-way point of
+    round(PI, 2) - which is also where int(float(PI)) meets the writers' threshold (:838-847) -, or a candidate's PI within
+    `eps` of the filter gate altPI >= 5 (:549).  The device's PI sits within ~ 3e-9 of the reference's arithmetic (other
+    summation order, own log / division routines), so a value this close to a boundary can land on its other side.  Nothing
+    is changed: the caller reports these loci (the command line logs them, bench.py counts them)."""
+    import numpy as np
+    ok = (rows["status"] & 0xff) == 0
+    vals = np.concatenate([rows["pi"], rows["cand"]["pi"]], axis=1)                 # [n, 6]
+    live = np.concatenate([np.ones_like(rows["pi"], bool), rows["cand"]["allele"] >= 0], axis=1) & np.isfinite(vals)
+    t = np.abs(vals) * 100.0
+    half = np.abs((t - np.floor(t)) - 0.5) < eps * 100.0
+    gate = np.abs(rows["cand"]["pi"] - 5.0) < eps
+    gate &= rows["cand"]["allele"] >= 0
+    return np.flatnonzero(ok & ((half & live).any(axis=1) | gate.any(axis=1)))

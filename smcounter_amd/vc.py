@@ -59,6 +59,7 @@ def vc_resident(rb, params: VcParams, refprov, eng: _engine.Engine) -> List[str]
         out_rows = plan.run_devbuf(rb.planes, params)
     finally:
         plan.close()
+    eng.last_rows = out_rows                  # (the command line looks at them once more: rows.pi_boundary_loci)
     return _strings(out_rows, rb, params, refprov)
 
 

@@ -78,7 +78,57 @@ def main():
         emit("synth_" + name, pb, synth.params_for(cfg), {cfg.chrom: seq})
 
 
+def main_giant():
+    """Barcodes with thousands of unpaired fragments: calProb's products (rightP = 0.9^n, smCounter.py:62-77) leave the double
+    range near n = 6,700 and the reference's own arithmetic decides what survives - one locus each with a barcode of 4,200
+    (above the per-count table, below the underflow), 6,600, 6,800 and 7,400 unpaired reference-allele fragments, a few of
+    another allele among them, next to ordinary barcodes."""
+    import numpy as np
+    from smcounter_amd.pileup import BASE_ALLELES, F_HAS_NM, F_READ1, F_READ2, F_REVERSE, PileupBatch
+    chroms = synth.stress_reference()
+    seq = chroms["chrT"]
+    rng = np.random.Generator(np.random.PCG64(4242))
+    cols = {k: [] for k in ("umi", "frag", "flag", "mq", "nm", "n_indel", "left_sp", "qlen", "qalen", "qpos", "indel", "is_del",
+                            "allele", "bq")}
+    chrom, pos, ref, alleles, off = [], [], [], [], [0]
+    for l, giant in enumerate((4200, 6600, 6800, 7400)):
+        p = 100 + 37 * l
+        r = seq[p - 1]
+        rid = BASE_ALLELES.index(r)
+        alt = BASE_ALLELES.index([c for c in "ATGC" if c != r][l % 3])
+        reads = []
+        for f in range(giant):                                    # barcode 0: unpaired fragments, mostly the reference allele
+            reads.append((0, f, rid if rng.random() > 0.001 else alt, int(rng.choice([25, 30, 37])), rng.random() < 0.5))
+        for u in range(1, 25):                                    # ordinary barcodes, some carrying the other allele
+            a = alt if u % 4 == 0 else rid
+            for f in range(int(rng.integers(1, 6))):
+                pair = rng.random() < 0.5
+                reads.append((u, f, a, int(rng.choice([25, 30, 37])), False))
+                if pair:
+                    reads.append((u, f, a, int(rng.choice([25, 30, 37])), True))
+        order = rng.permutation(len(reads))
+        umap, fmap = {}, {}
+        for i in order:
+            u, f, a, q, r2 = reads[int(i)]
+            f = fmap.setdefault(u, {}).setdefault(f, len(fmap[u]))       # ids by first appearance in the pileup
+            u = umap.setdefault(u, len(umap))
+            cols["umi"].append(u); cols["frag"].append(f)
+            cols["flag"].append((F_READ2 if r2 else F_READ1) | (F_REVERSE if r2 else 0) | F_HAS_NM)
+            cols["mq"].append(60); cols["nm"].append(0); cols["n_indel"].append(0); cols["left_sp"].append(0)
+            cols["qlen"].append(120); cols["qalen"].append(120); cols["qpos"].append(int(rng.integers(25, 100)))
+            cols["indel"].append(0); cols["is_del"].append(False); cols["allele"].append(a); cols["bq"].append(q)
+        chrom.append("chrT"); pos.append(p); ref.append(r); alleles.append(list(BASE_ALLELES)); off.append(len(cols["umi"]))
+    dt = dict(umi=np.uint32, frag=np.uint32, flag=np.uint8, mq=np.uint8, nm=np.uint32, n_indel=np.uint32, left_sp=np.uint32,
+              qlen=np.uint32, qalen=np.uint32, qpos=np.int32, indel=np.int32, is_del=bool, allele=np.uint8, bq=np.uint8)
+    pb = PileupBatch(chrom=chrom, pos=np.array(pos, np.int64), ref=ref, alleles=alleles, read_off=np.array(off, np.int64),
+                     **{k: np.array(v, dt[k]) for k, v in cols.items()})
+    emit("stress_giant", pb, VcParams(mtDepth=20000, rpb=8.6, hpLen=8, mtDrop=0), chroms)
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["giant"]:
+        main_giant()
+        sys.exit(0)
     if sys.argv[1:] == ["downsampled"]:
         main_downsampled()
     else:

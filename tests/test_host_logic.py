@@ -560,3 +560,32 @@ def test_native_lines_with_several_chromosomes_and_the_pass_rows_sequence():
     assert quick == plain and plain == quick and not (quick != plain)
     assert [quick[i] for i in range(n)] == plain and quick[2:7] == plain[2:7] and quick[-1] == plain[-1]
     assert quick.text == "\n".join(plain) + "\n"
+
+
+def test_loci_at_a_printing_boundary_are_reported():
+    """rows.pi_boundary_loci: a PI within 1e-8 of a round(PI, 2) half-way point or of the filter gate 5.0 is reported, values a
+    little further away are not, and the golden loci (whose strings the GPU tests compare with the reference's) have none."""
+    import glob
+    import oracle_lib
+    from smcounter_amd import abi, features, pileup, rows
+    from smcounter_amd.params import VcParams
+    r = np.zeros(8, abi.ROW_DTYPE)
+    r["cand"]["allele"] = -1
+    r["pi"][:] = 1.0
+    r["pi"][0, 1] = 12.345 + 4e-9            # half-way point of the second decimal
+    r["pi"][1, 2] = 57.995 - 2e-9            # half-way point where int(float(PI)) changes: the writers' threshold
+    r["cand"]["allele"][2, 0] = 1; r["cand"]["pi"][2, 0] = 5.0 - 3e-9     # the filter gate
+    r["cand"]["allele"][3, 0] = 1; r["cand"]["pi"][3, 0] = 5.0 + 1e-6     # clear of it
+    r["pi"][4, 0] = 12.345 + 1e-6            # clear of the half-way point
+    r["cand"]["pi"][5, 0] = 5.0              # no such candidate (allele -1)
+    r["status"][6] = 1; r["pi"][6, 0] = 0.005   # Zero_Coverage row: nothing printed
+    r["cand"]["allele"][7, 1] = 2; r["cand"]["pi"][7, 1] = 0.125 + 1e-10  # second candidate at a half-way point
+    assert rows.pi_boundary_loci(r).tolist() == [0, 1, 2, 7]
+    n = 0
+    for f in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "s*.npz"))):
+        pb, extra = pileup.load_npz(f)
+        P = VcParams(**extra["params"])
+        got = oracle_lib.call_batch(features.extract_features(pb, P), abi.c_params(P), abi.ROW_DTYPE)
+        assert rows.pi_boundary_loci(got).tolist() == []
+        n += len(got)
+    assert n > 600
