@@ -39,6 +39,10 @@ extern "C" {
 #define SMC_ST_ZERO_COVERAGE 1      /* usedMT == 0: the 45-field Zero_Coverage row, smCounter.py:492-494 */
 #define SMC_ST_DOWNSAMPLED 0x100    /* more barcodes than ds: reference would random.sample (:496-498) */
 #define SMC_ST_BAD_INPUT 0x200      /* an id in the batch was out of the range its descriptor declares */
+#define SMC_ST_UNDERFLOW 0x400      /* a barcode of the locus has so many fragments that calProb's products (smCounter.py:62-77:
+                                     * 0.9^n for unpaired fragments) left the normal double range (n > ~ 6,700): the reference's own
+                                     * posterior there is made of denormal rounding and depends on the order it multiplies in (py2
+                                     * dict order of read ids).  The row is computed; its PI / UMT columns are not pinned. */
 
 /* FILTER bits in smc_cand.flt, in the order filterVariants appends them (smCounter.py:187-266) */
 #define SMC_F_LM 0x001

@@ -261,6 +261,7 @@ static int call_locus(const smc_params* P, const smc_locus* L, const uint32_t* m
         for (int u = 0; u < nU && k < used; ++u) if (in_bc[u]) bc_order[k++] = u;
     }
     const double pcr_no_error = 1.0 - 3e-5;                              /* :20 */
+    int underflow = 0;
     fobs_t* obs = (fobs_t*)malloc(sizeof(fobs_t) * (size_t)(tot + 1));
     for (int b = 0; b < used; ++b) {                                     /* :506-532 */
         int u = bc_order[b], nf = 0;
@@ -294,6 +295,7 @@ static int call_locus(const smc_params* P, const smc_locus* L, const uint32_t* m
                 for (int k = 0; k < nk; ++k) if (keys[k] != base) prodP[keys[k]] *= prob;
                 rightP *= 1.0 - prob;
             }
+            if (rightP < 0x1p-1000) underflow = 1;   /* SMC_ST_UNDERFLOW: what follows is denormal rounding in this loop's order */
             for (int k = 0; k < nk; ++k) {                               /* :79-81 */
                 double ratio = (cnt[keys[k]] + 0.5) / (nf + 0.5 * nk);
                 pcrP[keys[k]] = pow(10.0, -6.0 * ratio);
@@ -354,6 +356,7 @@ static int call_locus(const smc_params* P, const smc_locus* L, const uint32_t* m
         }
         if (pass == 0) best = pick; else second = pick;
     }
+    if (underflow) R->status |= SMC_ST_UNDERFLOW;
     R->max_allele = best;
     R->second_allele = second;
     for (int k = 0; k < 4; ++k) { R->umt[k] = mtcnt[k]; R->vsm[k] = strong[k]; R->pi[k] = fin[k]; }

@@ -94,7 +94,7 @@ for rep in range(3):
     t = time.time()
     t_bld = t_run = 0.0
     out2, n_dev, n_host = cli._Rows(), 0, 0
-    it = devplanes.iter_resident_batches(bam, ref_f, loci, P, eng)
+    it = devplanes.iter_resident_batches(bam, ref_f, loci, P, eng, all_planes=False)
     while True:
         t1 = time.time()
         try:

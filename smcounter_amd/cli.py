@@ -67,7 +67,7 @@ class _EarlyEngine(object):
                 from . import _lib
                 from .engine import Engine
                 _lib.load(with_torch=False)
-                self._eng = Engine(device)
+                self._eng = _ENGINES.pop(device, None) or Engine(device)
             except BaseException as e:
                 self._err = e
         self._t = threading.Thread(target=work, daemon=True)
@@ -80,11 +80,25 @@ class _EarlyEngine(object):
         return self._eng
 
 
+_ENGINES = {}          # device -> Engine kept for the process's next run (smc_create + the first allocations are ~ 0.1 s)
+
+
+def _release_engine(eng):
+    """The engine stays with the process: a second main() in the same process finds the context, its tables and its buffers
+    again, and the command line does not spend 20 ms of its wall time freeing device memory the exiting process gives back
+    anyway (SMC_CLOSE_ENGINE=1: close it, as round 2 did)."""
+    if os.environ.get("SMC_CLOSE_ENGINE"):
+        _ENGINES.pop(eng.device, None)
+        eng.close()
+    else:
+        _ENGINES[eng.device] = eng
+
+
 def call_shard(args, params: VcParams, loci, device: int, early=None):
     """The per-locus rows (strings, smCounter.py:599) of a run of loci: BAM decode -> device batches -> kernels."""
     from .engine import Engine
     ref = fasta.FastaFile(args.refGenome)
-    eng = early.get() if early is not None else Engine(device)
+    eng = early.get() if early is not None else (_ENGINES.pop(device, None) or Engine(device))
     output = _Rows()
     decoder = os.environ.get("SMC_BAM_DECODER", "native")
     # (one process per GPU: the ranks of a node share its cores for decoding)
@@ -109,7 +123,7 @@ def call_shard(args, params: VcParams, loci, device: int, early=None):
         for first, rb in batches:
             output.add(vc.vc_resident(rb, params, ref, eng))
             _report_boundary(eng.last_rows, rb.chrom, rb.pos)
-        eng.close()
+        _release_engine(eng)
         return output.done()
     for first, pb in _prefetch(batches):
         output.add(vc.vc_batch(pb, params, ref, eng=eng))
@@ -153,6 +167,11 @@ def _report_boundary(out_rows, chrom, pos):
     idx = _rows.pi_boundary_loci(out_rows)
     for l in idx.tolist():
         print("note: prediction index of %s:%d lies within 1e-8 of a printing boundary" % (chrom[l], int(pos[l])))
+    import numpy as np
+    from . import abi
+    for l in np.flatnonzero((out_rows["status"] & abi.ST_UNDERFLOW) != 0).tolist():
+        print("note: a barcode at %s:%d has so many fragments that the posterior arithmetic left the double range; the "
+              "reference's own numbers there depend on its multiplication order" % (chrom[l], int(pos[l])))
 
 
 class _Rows(list):
