@@ -316,6 +316,7 @@ def main():
             out["cpu_baseline"], out["cpu_baseline_c"] = cpu["python_pool"], cpu["c_port"]
             out["cpu_baseline_c_all_cores"] = cpu["c_port_all_cores"]
             out["cpu_baseline_single_process"] = cpu["python_single"]
+            out["cpu_baseline_pool_chunked"] = cpu["python_pool_chunked"]
         if oracle is not None:
             res.run(rows)
             torch.cuda.synchronize()
@@ -411,6 +412,10 @@ def cpu_leg(a):
     t = time.perf_counter()
     got = vc_port.call_config(a.config, params, range(n_py), pool)
     dt_py = time.perf_counter() - t
+    n_ch = min(n, 40 * cores)
+    t = time.perf_counter()
+    vc_port.call_config_chunked(a.config, params, 0, n_ch, pool, 20)
+    dt_ch = time.perf_counter() - t
     pool.close()
     pool.join()
     want = vc_port.call_batch(sample, params, n_cpu=1, loci=range(4))
@@ -423,6 +428,9 @@ def cpu_leg(a):
                                   "multiprocessing.Pool(%d), one task per locus as smCounter.py:683-685, every worker making its own "
                                   "locus's input (the reference's worker reads its own BAM region), %.1f s (pool already started)"
                                   % (n_py, cores, dt_py)},
+        "python_pool_chunked": {"value": n_ch / dt_ch, "unit": "loci/s", "cores": phys, "logical_cpus": cores, "kind": "port",
+                                "sample": "first %d loci, the same pool with 20 consecutive loci per task, %.1f s: without the parent's "
+                                          "per-task round trip (~ 0.4 ms, invisible at the reference's 0.02 - 2 s per locus)" % (n_ch, dt_ch)},
         "python_single": {"value": n_one / dt_one, "unit": "loci/s", "cores": 1, "kind": "port",
                           "sample": "first %d loci, oracle/vc_port.py in this process (no pool), %.1f s; SURVEY.md section 6 timed the "
                                     "imported reference at ~51 loci/s on one core of the build container for this shape"

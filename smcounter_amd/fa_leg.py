@@ -153,6 +153,15 @@ def run_leg(eng, cfg_name: str, n_loci: int, steps: int, warmup: int, blocks: in
     # and CIGARs once per tile they touch (counted once here); umi_start and the descriptor per locus
     need = 2.0 * run.reads + 8.0 * slots + 36.0 * len(run.A["aln"]) + 4.0 * run.A["cig"].nbytes / 4 + 36.0 * run.nl
     n = max(1, run.t["n"])
+    # HBM bytes per launch of the walk from the committed PMC passes (profiles/traffic.json), over THIS run's kernel time
+    traffic, traffic_src = None, None
+    tpath = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        import json
+        rec = json.load(open(tpath)).get("fa:%s:%d" % (cfg_name, run.nl))
+        if rec:
+            traffic = rec["hbm_bytes_per_launch"] / (k_ms.value * 1e-3) / 1e9
+            traffic_src = "profiles/traffic.json <- " + rec.get("source", "rocprofv3 --pmc")
     out = {
         "workload": "%s-shaped alignments: %d loci, %d alignments (%d barcodes, %d fragments), %d pileup reads, depth %.0f; "
                     "resident in HBM (%.2f GB)" % (cfg_name, run.nl, len(run.A["aln"]), run.A["n_bc"], run.A["n_pair"], run.reads,
@@ -163,12 +172,12 @@ def run_leg(eng, cfg_name: str, n_loci: int, steps: int, warmup: int, blocks: in
         "pileup_reads_per_s": run.reads * steps / el,
         "host_ms_per_step": {k: round(v / n * 1e3, 3) for k, v in run.t.items() if k != "n"},
         "k_call_v2_ms": c_ms,
-        "roofline": {"bound": "hbm", "kernel": "k_bp_tiles<true> (the walk that writes the planes)", "kernel_ms": k_ms.value,
+        "roofline": {"bound": "hbm", "kernel": "k_bp_emit (the walk that writes the planes)", "kernel_ms": k_ms.value,
                      "kernel_samples": k_n.value, "needed_bytes_per_launch": need,
                      "achieved": need / (k_ms.value * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": need / (k_ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "frac_basis": "needed bytes: 2 B in + 8 B out per pileup read, alignment records and CIGARs once",
-                     "reads_per_s_kernel": run.reads / (k_ms.value * 1e-3), "traffic": None},
+                     "reads_per_s_kernel": run.reads / (k_ms.value * 1e-3), "traffic": traffic, "traffic_source": traffic_src},
         "builder_status": st,
         "generate_s": round(run.t_gen, 1),
     }
