@@ -8,7 +8,7 @@ import os
 from . import abi
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsmcounter_hip.so")
+LIB_PATH = os.environ.get("SMC_HIP_LIB") or os.path.join(HERE, "libsmcounter_hip.so")   # (SMC_HIP_LIB: another build of the same ABI - same-box A/B runs)
 
 SYMBOLS = ("smc_abi_version", "smc_last_error", "smc_row_size", "smc_locus_size", "smc_device_count",
            "smc_create", "smc_destroy", "smc_plan_create", "smc_plan_create_dev", "smc_plan_destroy", "smc_plan_info",

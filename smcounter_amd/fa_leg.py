@@ -27,7 +27,10 @@ class AlignmentRun(object):
     def __init__(self, eng, cfg, params, n_loci, nthreads):
         self.eng, self.cfg, self.params = eng, cfg, params
         t0 = time.time()
-        A = synth.generate_alignments(cfg, n_loci, params, nthreads=nthreads)
+        kw = {}
+        if os.environ.get("SMC_FA_INDEL_RATE"):                              # (experiments: the share of alignments with an insertion / a deletion)
+            kw = dict(p_ins_aln=float(os.environ["SMC_FA_INDEL_RATE"]), p_del_aln=float(os.environ["SMC_FA_INDEL_RATE"]))
+        A = synth.generate_alignments(cfg, n_loci, params, nthreads=nthreads, **kw)
         self.t_gen = time.time() - t0
         self.A = A
         self.nl, self.ns, self.lo = A["nl"], A["n_slots"], int(A["start0"])
