@@ -44,17 +44,18 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 
 
 def needed_bytes(loci) -> float:
-    """HBM bytes one launch of the hot path has to move for these loci: the two planes the kernels read
-    (meta, frag: 8 B per read slot), umi_start, the 32-byte descriptor + 4-byte launch-order entry, and the row written."""
+    """HBM bytes one launch of the hot path has to move for these loci: the read words (one uint32 per read slot: allele,
+    quality, fragment start, class), umi_start, the 32-byte descriptor + 4-byte launch-order entry, and the row written."""
     import numpy as np
     from smcounter_amd import abi
     slots = ((loci["n_reads"].astype(np.int64) + 3) // 4 * 4).sum()
-    return float(8 * slots + 4 * (loci["n_umi"].astype(np.int64) + 1).sum() + (32 + 4 + abi.ROW_DTYPE.itemsize) * len(loci))
+    return float(4 * slots + 4 * (loci["n_umi"].astype(np.int64) + 1).sum() + (32 + 4 + abi.ROW_DTYPE.itemsize) * len(loci))
 
 
 class Resident(object):
-    """One config's batch resident in HBM: the planes the kernels read + the plan; optionally the CPU restatement's rows
-    of every chunk (all host cores), kept for the parity pass."""
+    """One config's batch resident in HBM: what the kernels read - the read words (packed on the device from the synthetic
+    batch's meta and frag planes, smc_pack_words, before anything is timed) and umi_start - + the plan; optionally the CPU
+    restatement's rows of every chunk (all host cores), kept for the parity pass."""
 
     def __init__(self, eng, cfg, params, lo, hi, chunk, nthreads, dev, oracle=None):
         import numpy as np
@@ -62,8 +63,8 @@ class Resident(object):
         from smcounter_amd import abi, synth
         n_loc = hi - lo
         stride = (cfg.depth + 3) // 4 * 4
-        self.meta = torch.empty(n_loc * stride, dtype=torch.int32, device=dev)
-        self.frag = torch.empty(n_loc * stride, dtype=torch.int32, device=dev)
+        meta = torch.empty(n_loc * stride, dtype=torch.int32, device=dev)
+        frag = torch.empty(n_loc * stride, dtype=torch.int32, device=dev)
         self.umi_start = torch.empty(n_loc * (cfg.n_umi + 1), dtype=torch.int32, device=dev)
         loci_parts, self.want = [], []
         for c0 in range(lo, hi, chunk):
@@ -71,8 +72,8 @@ class Resident(object):
             db = synth.generate_native(cfg, c0, c1, params, nthreads=nthreads)
             off = (c0 - lo) * stride
             # (the umi and dist planes hold the raw fields the CPU restatement reads; the kernels do not: smcounter_hip.h)
-            self.meta[off:off + db.n_slots].copy_(torch.from_numpy(db.meta.view(np.int32)))
-            self.frag[off:off + db.n_slots].copy_(torch.from_numpy(db.frag.view(np.int32)))
+            meta[off:off + db.n_slots].copy_(torch.from_numpy(db.meta.view(np.int32)))
+            frag[off:off + db.n_slots].copy_(torch.from_numpy(db.frag.view(np.int32)))
             uoff = (c0 - lo) * (cfg.n_umi + 1)
             self.umi_start[uoff:uoff + len(db.umi_start)].copy_(torch.from_numpy(db.umi_start.view(np.int32)))
             if oracle is not None:
@@ -84,7 +85,11 @@ class Resident(object):
             loci_parts.append(loc)
         self.loci = np.concatenate(loci_parts)
         self.plan = eng.make_plan(self.loci)
-        self.planes = [self.meta, self.meta, self.frag, self.meta, self.umi_start]   # umi / dist slots: never dereferenced
+        self.words = torch.empty(n_loc * stride, dtype=torch.int32, device=dev)
+        self.plan.pack_words(meta, frag, self.words)
+        torch.cuda.synchronize()
+        del meta, frag
+        self.planes = [self.words, self.umi_start]
         self.params = params
 
     def run(self, rows):
@@ -113,14 +118,14 @@ class Resident(object):
 
     def close(self):
         self.plan.close()
-        self.meta = self.frag = self.umi_start = self.planes = None
+        self.words = self.umi_start = self.planes = None
 
 
 def roofline_block(plan_loci, k_ms, k_n, k_loci, k_reads, cfg_key):
-    """`achieved` / `frac`: the bytes the dominant kernel HAS to move per launch (the two planes it reads - 8 B per read slot -,
+    """`achieved` / `frac`: the bytes the dominant kernel HAS to move per launch (the read words - 4 B per read slot -,
     umi_start, descriptors, rows) over its mean HIP-event duration, against the 8 TB/s peak.  SURVEY.md 8d's algorithmic figure
-    (16 B per read + 360 B per locus: the four planes of the layout, of which the kernels read two - the plane builder digests
-    the other two into the read class) is kept beside it as achieved_survey_8d / frac_survey_8d; it can exceed what a copy
+    (16 B per read + 360 B per locus: the four raw-field planes of the layout, which the plane builder digests into the one
+    word per read the kernels load) is kept beside it as achieved_survey_8d / frac_survey_8d; it can exceed what a copy
     achieves on this part and is not a fraction of anything the kernel does."""
     alg_bytes = 16.0 * k_reads + 360.0 * k_loci              # per launch of the dominant kernel (SURVEY 8d)
     need = needed_bytes(plan_loci)
@@ -137,14 +142,14 @@ def roofline_block(plan_loci, k_ms, k_n, k_loci, k_reads, cfg_key):
             src = "profiles/traffic.json <- " + rec.get("source", "rocprofv3 --pmc")
     return {"bound": "hbm", "kernel": "k_call_v2", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "frac_basis": "needed bytes per launch (8 B per read slot + umi_start + descriptor + row) / kernel time / 8 TB/s",
+            "frac_basis": "needed bytes per launch (4 B per read slot: the read word; + umi_start + descriptor + row) / kernel time / 8 TB/s",
             "traffic": traffic, "traffic_source": src,
             "kernel_ms": k_ms, "kernel_samples": k_n, "loci_per_launch": k_loci,
             "needed_bytes_per_launch": need, "hbm_bytes_per_launch_pmc": traffic_bytes,
             "alg_bytes_per_launch_survey_8d": alg_bytes, "achieved_survey_8d": alg_bytes / (k_ms * 1e-3) / 1e9,
             "frac_survey_8d": alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "note": "frac_survey_8d counts SURVEY 8d's 16 B/read; the kernels load 8 B/read (meta + frag planes), the other 8 are "
-                    "consumed by the plane builder (the from_alignments leg times it)"}
+            "note": "frac_survey_8d counts SURVEY 8d's 16 B/read (four raw-field planes); the kernels load 4 B/read - the read word "
+                    "the plane builder folds them into (the from_alignments leg times it; rounds 1-3 loaded 8 B/read: meta + frag)"}
 
 
 def physical_cores():

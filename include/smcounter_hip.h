@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SMC_ABI_VERSION 3
+#define SMC_ABI_VERSION 4
 #define SMC_MAX_ALLELES 64 /* allele ids per locus; ids 0-5 are A,T,G,C,N,'DEL' */
 
 /* error codes */
@@ -84,6 +84,14 @@ extern "C" {
 #define SMC_FRAG_SLOT_MASK 0x07FFFFFFu
 #define SMC_FRAG_CLASS_SHIFT 27
 #define SMC_N_READ_CLASS 22
+/* The read word: what the locus kernels read, ONE uint32 per read (4 of the raw-field planes' 16 bytes cross HBM).
+ *   bits 0-7 allele id, 8-15 base quality (<= 126; minBQ for a read inside a deletion) - the low half of the meta word;
+ *   bit 16 the read is the first of its fragment at this locus (the fragment slots are dense and ascending, so the slot
+ *          number itself carries nothing else); bits 17-26 zero; bits 27-31 the read class (as in the frag word).
+ * smc_build_planes writes it directly; smc_pack_words folds a batch's meta and frag planes into it (and checks the slot
+ * contract, which the words can no longer break); smc_plan_run_words runs on it. */
+#define SMC_RW_NF 0x00010000u
+#define SMC_RW_CLASS_SHIFT 27
 #if defined(__HIPCC__)
 #define SMC_HOST_DEVICE __host__ __device__   /* (the device plane builder evaluates it too) */
 #else
@@ -305,6 +313,13 @@ int smc_plan_kernel_ms(smc_plan* plan, float* avg_ms, int32_t* n_samples, int64_
 int smc_plan_run(smc_plan* plan, const smc_params* params, const uint32_t* meta,
                  const uint32_t* umi, const uint32_t* frag, const uint32_t* dist,
                  const uint32_t* umi_start, smc_row* rows, void* stream);
+/* The same on read words (smc_read_word above; n_slots x uint32): the form the kernels read.  smc_plan_run is
+ * smc_pack_words into a buffer the plan keeps + this call.  smc_locus.n_frag is taken as given (allFrag of the row): the
+ * words carry the fragment boundaries, not their count. */
+int smc_plan_run_words(smc_plan* plan, const smc_params* params, const uint32_t* words, const uint32_t* umi_start,
+                       smc_row* rows, void* stream);
+/* meta + frag planes of the plan's batch -> read words (device pointers; asynchronous on `stream`) */
+int smc_pack_words(smc_plan* plan, const uint32_t* meta, const uint32_t* frag, uint32_t* words, void* stream);
 
 /* Convenience for callers without their own device buffers: host pointers in, host rows out
  * (synchronous; does H2D, smc_plan_run, D2H). */
@@ -324,8 +339,9 @@ int smc_unpack_rows(const smc_wire_row* wire, int64_t n, smc_row* rows);
  * smc_bam_alignments): per locus the covering alignments in file order, per read the CIGAR walk, allele, quality, flags,
  * end distances and read class (smCounter.py:316-366, :371-452), barcode / fragment ids by first appearance (:462-471),
  * the barcode-major order, umi_start and the descriptor - byte for byte what smc_bam_planes builds on the host.
- * Everything in `in` and every output is a DEVICE pointer.  Outputs: the four planes (the run's slots start at
- * slot_base; `umi` and `dist` - the raw fields the locus kernels do not read - may be NULL: not written then), umi_start / u_gid / u_finc (sized slots + loci of the batch; locus l of the run uses
+ * Everything in `in` and every output is a DEVICE pointer.  Outputs: the read words (the run's slots start at slot_base) and /
+ * or the four raw-field planes (any of the five may be NULL - not written then - as long as `words`, or `meta` and `frag`, is
+ * there; the raw-field planes are for checks: with only `words` the walk stages and stores a quarter of the bytes), umi_start / u_gid / u_finc (sized slots + loci of the batch; locus l of the run uses
  * [umi_base + slot_off(l) + l, ... + n_umi(l)]; u_gid / u_finc - run-wide barcode id and first INCLUDED pileup index per
  * barcode - are filled only for loci with more barcodes than params->ds: what the host needs for the reference's
  * down-sampling, :496-498), loci[n_loci] (read_off4 / umi_off already batch-relative), and for every allele beyond the six
@@ -352,8 +368,8 @@ int smc_build_max_depth(void);
 int smc_build_set_timing(smc_ctx* ctx, int slots);
 int smc_build_kernel_ms(smc_ctx* ctx, float* avg_ms, int32_t* n_samples);
 int smc_build_planes(smc_ctx* ctx, const smc_params* params, const smc_build_in* in, uint32_t slot_base, uint32_t umi_base,
-                     uint32_t* meta, uint32_t* umi, uint32_t* frag, uint32_t* dist, uint32_t* umi_start, uint32_t* u_gid,
-                     uint32_t* u_finc, smc_locus* loci, uint32_t* xlist, uint32_t xcap, uint32_t* counters, void* stream);
+                     uint32_t* words, uint32_t* meta, uint32_t* umi, uint32_t* frag, uint32_t* dist, uint32_t* umi_start,
+                     uint32_t* u_gid, uint32_t* u_finc, smc_locus* loci, uint32_t* xlist, uint32_t xcap, uint32_t* counters, void* stream);
 
 /* Device memory for callers without a GPU runtime of their own (the Python command line uses these instead of importing
  * PyTorch: about a second of start-up): allocation, synchronous copies, device synchronisation. */

@@ -20,7 +20,7 @@ for path in libs:
     L.smc_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
     L.smc_last_error.restype = ctypes.c_char_p
     L.smc_build_planes.argtypes = [vp, ctypes.POINTER(abi.SmcParams), ctypes.POINTER(abi.SmcBuildIn), ctypes.c_uint32, ctypes.c_uint32,
-                                   vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int64, vp, vp]
+                                   vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int64, vp, vp]
     L.smc_build_set_timing.argtypes = [vp, ctypes.c_int]
     L.smc_build_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32)]
     L.smc_device_sync.argtypes = [vp]
@@ -30,7 +30,7 @@ for path in libs:
 
 
 def build(L, ctx):
-    rc = L.smc_build_planes(ctx, ctypes.byref(run.cp), ctypes.byref(run.bi), 0, 0, run.meta.data_ptr(), None, run.frag.data_ptr(), None,
+    rc = L.smc_build_planes(ctx, ctypes.byref(run.cp), ctypes.byref(run.bi), 0, 0, run.words.data_ptr(), None, None, None, None,
                             run.uaux[0].data_ptr(), run.uaux[1].data_ptr(), run.uaux[2].data_ptr(), run.d_loci.data_ptr(),
                             run.d_x.data_ptr(), run.xcap, run.d_cnt.data_ptr(), None)
     assert rc == 0, L.smc_last_error()
@@ -54,8 +54,8 @@ for rnd in range(5):
         if rnd:
             res[path][0].append(k_ms.value); res[path][1].append(wall)
         if rnd == 0:   # the planes every library wrote (same numbering rules -> same bytes)
-            m = run.meta.download(np.uint32, min(run.ns, 1 << 24)); f = run.frag.download(np.uint32, min(run.ns, 1 << 24))
-            sig[path] = (int(m.astype(np.uint64).sum()), int(f.astype(np.uint64).sum()), run.status())
+            m = run.words.download(np.uint32, min(run.ns, 1 << 24))
+            sig[path] = (int(m.astype(np.uint64).sum()), run.status())
 for path in libs:
     e, w = res[path]
     print("%-24s k_bp_emit %s ms (median %.3f)   whole build %.3f ms   planes checksum %s" % (

@@ -36,7 +36,7 @@ up = lambda a: DevBuf(eng, a.nbytes + 64).upload(a.view(np.uint8).reshape(-1))
 d_aln, d_cig, d_seq, d_qual, d_loc = up(A["aln"]), up(A["cig"]), up(A["seq"]), up(A["qual"]), up(A["loc"])
 run_ref = ref_f.fetch(chrom, lo, hi).upper()
 d_ref = up(np.frombuffer(run_ref[:nl].encode().ljust(nl, b"\0"), np.uint8).copy())
-planes = [DevBuf(eng, 4 * ns) if (all_planes or k in (0, 2)) else None for k in range(4)]
+planes = [DevBuf(eng, 4 * ns)] + [DevBuf(eng, 4 * ns) if all_planes else None for k in range(4)]   # words, meta, umi, frag, dist
 uaux = [DevBuf(eng, 4 * (ns + nl + 8)) for _ in range(3)]
 d_loci = DevBuf(eng, nl * LOCUS_DTYPE.itemsize)
 xcap = 4 * nl + 4096
@@ -46,9 +46,8 @@ bi = abi.SmcBuildIn(d_aln.data_ptr(), d_cig.data_ptr(), d_seq.data_ptr(), d_qual
                     lo, nl, A["n_bc"], A["n_pair"], int(A["loc"]["n"].max()), len(A["aln"]), loc_host.ctypes.data)
 cp = abi.c_params(P)
 def call():
-    _lib.check(L.smc_build_planes(eng.ctx, ctypes.byref(cp), ctypes.byref(bi), 0, 0, planes[0].data_ptr(),
-                                  planes[1].data_ptr() if planes[1] is not None else None, planes[2].data_ptr(),
-                                  planes[3].data_ptr() if planes[3] is not None else None, uaux[0].data_ptr(),
+    pp = [t.data_ptr() if t is not None else None for t in planes]
+    _lib.check(L.smc_build_planes(eng.ctx, ctypes.byref(cp), ctypes.byref(bi), 0, 0, pp[0], pp[1], pp[2], pp[3], pp[4], uaux[0].data_ptr(),
                                   uaux[1].data_ptr(), uaux[2].data_ptr(), d_loci.data_ptr(), d_x.data_ptr(), xcap,
                                   d_cnt.data_ptr(), ctypes.c_void_p(0)), "smc_build_planes")
 for _ in range(3):
@@ -67,4 +66,4 @@ ms = ctypes.c_float()
 L.smc_event_elapsed_ms(e0, e1, ctypes.byref(ms))
 ms = ms.value / reps
 print("smc_build_planes (%d planes): %.3f ms per run (host issue %.3f ms) -> %.1f G pileup reads/s; status %s" % (
-    4 if all_planes else 2, ms, t_host * 1e3, reads / ms / 1e6, d_cnt.download(np.uint32, 2).tolist()))
+    5 if all_planes else 1, ms, t_host * 1e3, reads / ms / 1e6, d_cnt.download(np.uint32, 2).tolist()))

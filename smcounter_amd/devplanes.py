@@ -32,7 +32,8 @@ _TIMES = {"decode": 0.0, "upload+launch": 0.0, "kernel (sync)": 0.0}      # SMC_
 class ResidentBatch:
     """A batch whose planes live in HBM (engine.DevBuf allocations: no PyTorch in this path); the descriptors and what row
     formatting needs are on the host."""
-    planes: list               # [meta, umi, frag, dist, umi_start] device buffers (`data_ptr()`), uint32 words
+    planes: list               # [meta, umi, frag, dist, umi_start] device buffers (`data_ptr()`), uint32 words; the four
+                               # raw-field planes are None when the batch was built with all_planes=False
     loci: np.ndarray           # LOCUS_DTYPE[n_loci] (host copy; offsets are batch-relative)
     chrom: List[str]
     pos: np.ndarray
@@ -42,6 +43,7 @@ class ResidentBatch:
     n_host_runs: int = 0
     n_slots: int = 0
     n_ustart: int = 0
+    words: object = None       # the read words (one uint32 per read: what the locus kernels read), device buffer
 
     @property
     def n_loci(self) -> int:
@@ -56,11 +58,30 @@ class ResidentBatch:
                            pos=self.pos.copy(), ref=list(self.ref), alleles=[list(t) for t in self.alleles])
 
 
+def pack_words_host(meta: np.ndarray, frag: np.ndarray, loci: np.ndarray) -> np.ndarray:
+    """The read words (include/smcounter_hip.h: smc_read_word) of a host-built batch, as smc_pack_words makes them on the device:
+    allele and quality from the meta word, the class from the frag word, "first read of its fragment" from the slots."""
+    from .features import FRAG_SLOT_MASK, FRAG_CLASS_SHIFT
+    ns = len(meta)
+    slot = frag & np.uint32(FRAG_SLOT_MASK)
+    nf = np.ones(ns, bool)
+    nf[1:] = slot[1:] != slot[:-1]
+    start = 4 * loci["read_off4"].astype(np.int64)
+    n = loci["n_reads"].astype(np.int64)
+    nf[start[n > 0]] = True
+    d = np.zeros(ns + 1, np.int64)
+    np.add.at(d, start, 1)
+    np.add.at(d, start + n, -1)
+    valid = np.cumsum(d[:-1]) > 0
+    w = (meta & np.uint32(0xFFFF)) | (nf.astype(np.uint32) << np.uint32(16)) | ((frag >> np.uint32(FRAG_CLASS_SHIFT)) << np.uint32(27))
+    return np.where(valid, w, np.uint32(0)).astype(np.uint32)
+
+
 def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], params, eng, max_reads: int = 32_000_000,
                           nthreads: int = 0, force_host: bool = False, all_planes: bool = True):
     """BAM -> `ResidentBatch` chunks: same loci per chunk as bamio.iter_device_batches_native, planes built on the GPU.
-    `all_planes=False`: only the planes the locus kernels read (meta, frag) and umi_start are built and kept - half the
-    device memory of a batch; the `umi` and `dist` planes (raw fields, for checks) are then absent (None)."""
+    `all_planes=False`: only what the locus kernels read - the read words and umi_start - is built and kept (a fifth of the
+    device memory of a batch, a quarter of the builder's stores); the four raw-field planes (for checks) are then None."""
     from .engine import DevBuf
     L = eng.L
     bam = bamio.NativeBam(path)
@@ -81,7 +102,8 @@ def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], par
     per_locus = 0.0          # pileup reads per locus of the previous run: sizes the next run (a run is decoded as a whole)
     while i < n:
         first = i
-        planes = [DevBuf(eng, 4 * cap) if (all_planes or k in (0, 2)) else None for k in range(4)]
+        planes = [DevBuf(eng, 4 * cap) if all_planes else None for k in range(4)]
+        words = DevBuf(eng, 4 * cap)
         uaux = [DevBuf(eng, 4 * (cap + 8192)) for _ in range(3)]      # umi_start, u_gid, u_finc
         LC, chroms, poss, refs, tables = [], [], [], [], []
         total = slots = n_loc = 0
@@ -108,7 +130,7 @@ def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], par
             umi_base = slots + n_loc
             done = None
             if not force_host:
-                done = _device_run(bam, L, eng, cp, params, chrom, lo, hi, max_reads - total, nthreads, fasta, run_ref, planes, uaux,
+                done = _device_run(bam, L, eng, cp, params, chrom, lo, hi, max_reads - total, nthreads, fasta, run_ref, [words] + planes, uaux,
                                    slots, umi_base, cap, max_depth)
             if done is None:
                 # host builder (the run is not one the device path takes): same planes, uploaded
@@ -119,6 +141,7 @@ def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], par
                 for k in range(4):
                     if planes[k] is not None:
                         planes[k].upload(hp[k], 4 * slots)
+                words.upload(pack_words_host(hp[0], hp[2], lc), 4 * slots)
                 uaux[0].upload(ustart, 4 * umi_base)
                 lc = lc.copy()
                 lc["read_off4"] += slots // 4
@@ -140,7 +163,7 @@ def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], par
             i += nl
         lc_all = LC[0] if len(LC) == 1 else np.concatenate(LC)
         uaux[1].free(); uaux[2].free()
-        yield first, ResidentBatch(planes=planes + [uaux[0]], n_slots=slots, n_ustart=slots + n_loc + 1,
+        yield first, ResidentBatch(planes=planes + [uaux[0]], words=words, n_slots=slots, n_ustart=slots + n_loc + 1,
                                    loci=lc_all, chrom=chroms, pos=poss[0] if len(poss) == 1 else np.concatenate(poss) if poss else np.zeros(0, np.int64),
                                    ref=refs, alleles=tables,
                                    n_device_runs=n_dev, n_host_runs=n_host)
@@ -164,7 +187,7 @@ def _device_run(bam, L, eng, cp, params, chrom, lo, hi, max_reads, nthreads, fas
 def build_run(A, L, eng, cp, params, chrom, lo, fasta, run_ref, planes, uaux, slot_base, umi_base, cap, max_depth,
               allele_key, barcode_name, stream_sync=True):
     """smc_build_planes over one run's alignments `A` (bamio.NativeBam.alignments_run or synth.generate_alignments) into the
-    batch's device arrays.  `allele_key(ai, qpos, indel)` / `barcode_name(gid)` give the texts the host needs (indel allele
+    batch's device arrays (`planes`: [words, meta, umi, frag, dist], any of them None).  `allele_key(ai, qpos, indel)` / `barcode_name(gid)` give the texts the host needs (indel allele
     keys, barcode names for the reference's down-sampling)."""
     import time
     from .engine import DevBuf
@@ -187,9 +210,9 @@ def build_run(A, L, eng, cp, params, chrom, lo, fasta, run_ref, planes, uaux, sl
     loc_host = np.ascontiguousarray(A["loc"])          # (the windows size the sort and the launch grids: read on the host)
     bi = abi.SmcBuildIn(d_aln.data_ptr(), d_cig.data_ptr(), d_seq.data_ptr(), d_qual.data_ptr(), d_loc.data_ptr(), d_ref.data_ptr(),
                         lo, nl, A["n_bc"], A["n_pair"], deepest, len(A["aln"]), loc_host.ctypes.data)
-    _lib.check(L.smc_build_planes(eng.ctx, ctypes.byref(cp), ctypes.byref(bi), slot_base, umi_base, planes[0].data_ptr(),
-                                  planes[1].data_ptr() if planes[1] is not None else None, planes[2].data_ptr(),
-                                  planes[3].data_ptr() if planes[3] is not None else None, uaux[0].data_ptr(),
+    pp = [t.data_ptr() if t is not None else None for t in planes]     # [words, meta, umi, frag, dist]
+    _lib.check(L.smc_build_planes(eng.ctx, ctypes.byref(cp), ctypes.byref(bi), slot_base, umi_base, pp[0], pp[1], pp[2], pp[3], pp[4],
+                                  uaux[0].data_ptr(),
                                   uaux[1].data_ptr(), uaux[2].data_ptr(), d_loci.data_ptr(), d_x.data_ptr(), xcap,
                                   d_cnt.data_ptr(), ctypes.c_void_p(0)), "smc_build_planes")
     t2 = time.perf_counter()
@@ -269,17 +292,18 @@ def resident_from_alignments(A, eng, params, all_planes: bool = True, chrom: str
     chrom = chrom or synth.ALN_CHROM
     nl, ns, lo = A["nl"], A["n_slots"], int(A["start0"])
     cap = ns + 64
-    planes = [DevBuf(eng, 4 * cap) if (all_planes or k in (0, 2)) else None for k in range(4)]
+    planes = [DevBuf(eng, 4 * cap) if all_planes else None for k in range(4)]
+    words = DevBuf(eng, 4 * cap)
     uaux = [DevBuf(eng, 4 * (cap + nl + 8192)) for _ in range(3)]
     run_ref = synth.aln_ref_fetch(lo, lo + nl)
     ref = synth.CyclicRef()
-    done = build_run(A, L, eng, abi.c_params(params), params, chrom, lo, ref, run_ref, planes, uaux, 0, 0, cap + nl,
+    done = build_run(A, L, eng, abi.c_params(params), params, chrom, lo, ref, run_ref, [words] + planes, uaux, 0, 0, cap + nl,
                      L.smc_build_max_depth(), synth_allele_key(A), lambda gid: "B%d" % gid)
     if done is None:
         raise RuntimeError("smc_build_planes did not take the run (status / size)")
     nl, ns, lc, tb = done
     uaux[1].free(); uaux[2].free()
-    return ResidentBatch(planes=planes + [uaux[0]], n_slots=ns, n_ustart=ns + nl + 1, loci=lc, chrom=[chrom] * nl,
+    return ResidentBatch(planes=planes + [uaux[0]], words=words, n_slots=ns, n_ustart=ns + nl + 1, loci=lc, chrom=[chrom] * nl,
                          pos=np.arange(lo + 1, lo + 1 + nl, dtype=np.int64), ref=list(run_ref), alleles=tb, n_device_runs=1)
 
 

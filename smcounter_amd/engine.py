@@ -177,15 +177,35 @@ class Plan(object):
         return torch.empty(self.n_loci * abi.ROW_DTYPE.itemsize, dtype=torch.uint8,
                            device=torch.device("cuda", self.eng.device))
 
+    def _stream_ptr(self, stream):
+        if stream == 0:
+            return ctypes.c_void_p(0)
+        import torch
+        st = stream if stream is not None else torch.cuda.current_stream(self.eng.device)
+        return ctypes.c_void_p(st.cuda_stream)
+
+    def pack_words(self, meta, frag, words, stream=None):
+        """meta + frag planes of the plan's batch -> read words (smc_pack_words; one uint32 per read, what the kernels read)."""
+        _lib.check(self.eng.L.smc_pack_words(self.h, meta.data_ptr(), frag.data_ptr(), words.data_ptr(), self._stream_ptr(stream)),
+                   "smc_pack_words")
+        return words
+
+    def run_words(self, words, umi_start, params: VcParams, rows=None, stream=None):
+        """The hot path on read words (smc_plan_run_words): what smc_build_planes writes, or pack_words has made."""
+        if rows is None:
+            rows = self.alloc_rows()
+        cp = abi.c_params(params)
+        _lib.check(self.eng.L.smc_plan_run_words(self.h, ctypes.byref(cp), words.data_ptr(), umi_start.data_ptr(), rows.data_ptr(),
+                                                 self._stream_ptr(stream)), "smc_plan_run_words")
+        return rows
+
     def run(self, planes, params: VcParams, rows=None, stream=None):
         """Enqueue the hot path on `stream` (a torch.cuda.Stream; default: torch's current one; 0: the default HIP stream,
-        without touching torch - the DevBuf path)."""
-        if stream == 0:
-            st_ptr = ctypes.c_void_p(0)
-        else:
-            import torch
-            st = stream if stream is not None else torch.cuda.current_stream(self.eng.device)
-            st_ptr = ctypes.c_void_p(st.cuda_stream)
+        without touching torch - the DevBuf path).  `planes`: [meta, umi, frag, dist, umi_start] (the raw-field planes: packed
+        into read words first, smc_plan_run) or [words, umi_start]."""
+        if len(planes) == 2:
+            return self.run_words(planes[0], planes[1], params, rows, stream)
+        st_ptr = self._stream_ptr(stream)
         if rows is None:
             rows = self.alloc_rows()
         cp = abi.c_params(params)

@@ -1,6 +1,6 @@
 """bench.py's `from_alignments` leg: the hot path timed from where the reference's hot loop starts (smCounter.py:316) - a run's
 ALIGNMENTS resident in HBM (what the BAM decoder hands over) -> smc_build_planes (sort, count, scan, the walk that writes the
-planes: csrc/k_build_planes.inc) -> smc_plan_create_dev (launch plan made where the descriptors are) -> smc_plan_run -> rows in HBM.
+planes: csrc/k_build_planes.inc) -> smc_plan_create_dev (launch plan made where the descriptors are) -> smc_plan_run_words -> rows in HBM.
 
 Not part of the product path: a measurement harness (and its parity check against the decoder + host builder + CPU
 restatement on a bounded sample).
@@ -21,8 +21,8 @@ HBM_PEAK_GBS = 8000.0
 
 
 class AlignmentRun(object):
-    """A run of synthetic alignments resident in HBM + the output arrays of smc_build_planes (only the planes the locus kernels
-    read: meta and frag)."""
+    """A run of synthetic alignments resident in HBM + the output arrays of smc_build_planes (only what the locus kernels read:
+    the read words)."""
 
     def __init__(self, eng, cfg, params, n_loci, nthreads):
         self.eng, self.cfg, self.params = eng, cfg, params
@@ -39,7 +39,7 @@ class AlignmentRun(object):
         self.d_in = [up(A[k]) for k in ("aln", "cig", "seq", "qual", "loc")]
         run_ref = synth.aln_ref_fetch(self.lo, self.lo + self.nl)
         self.d_ref = up(np.frombuffer(run_ref.encode(), np.uint8).copy())
-        self.meta, self.frag = DevBuf(eng, 4 * (self.ns + 64)), DevBuf(eng, 4 * (self.ns + 64))
+        self.words = DevBuf(eng, 4 * (self.ns + 64))
         self.uaux = [DevBuf(eng, 4 * (self.ns + self.nl + 64)) for _ in range(3)]
         self.d_loci = DevBuf(eng, self.nl * LOCUS_DTYPE.itemsize)
         self.xcap = 4 * self.nl + 4096
@@ -63,8 +63,8 @@ class AlignmentRun(object):
         """build -> descriptors -> plan -> run; everything the product path does between the decoder and the rows."""
         eng, L = self.eng, self.eng.L
         t0 = time.perf_counter()
-        _lib.check(L.smc_build_planes(eng.ctx, ctypes.byref(self.cp), ctypes.byref(self.bi), 0, 0, self.meta.data_ptr(), None,
-                                      self.frag.data_ptr(), None, self.uaux[0].data_ptr(), self.uaux[1].data_ptr(),
+        _lib.check(L.smc_build_planes(eng.ctx, ctypes.byref(self.cp), ctypes.byref(self.bi), 0, 0, self.words.data_ptr(), None, None,
+                                      None, None, self.uaux[0].data_ptr(), self.uaux[1].data_ptr(),
                                       self.uaux[2].data_ptr(), self.d_loci.data_ptr(), self.d_x.data_ptr(), self.xcap,
                                       self.d_cnt.data_ptr(), ctypes.c_void_p(0)), "smc_build_planes")
         t1 = time.perf_counter()
@@ -76,7 +76,7 @@ class AlignmentRun(object):
             t2 = t1
             plan = eng.make_plan_dev(self.d_loci, self.nl)            # binned where the descriptors are (waits for the builder)
         t3 = time.perf_counter()
-        plan.run([self.meta, None, self.frag, None, self.uaux[0]], self.params, self.rows, stream=0)
+        plan.run([self.words, self.uaux[0]], self.params, self.rows, stream=0)
         t4 = time.perf_counter()
         T = self.t
         T["build_issue"] += t1 - t0; T["descriptors_d2h"] += t2 - t1; T["plan_create"] += t3 - t2; T["run_issue"] += t4 - t3; T["n"] += 1
@@ -88,7 +88,7 @@ class AlignmentRun(object):
         return self.d_cnt.download(np.uint32, 2).tolist()
 
     def close(self):
-        for b in self.d_in + [self.d_ref, self.meta, self.frag, self.d_loci, self.d_x, self.d_cnt, self.rows] + self.uaux:
+        for b in self.d_in + [self.d_ref, self.words, self.d_loci, self.d_x, self.d_cnt, self.rows] + self.uaux:
             b.free()
         self.A = None
 
@@ -147,14 +147,14 @@ def run_leg(eng, cfg_name: str, n_loci: int, steps: int, warmup: int, blocks: in
     L.smc_device_sync(eng.ctx)
     plan.set_timing(8)
     for _ in range(8):
-        plan.run([run.meta, None, run.frag, None, run.uaux[0]], params, run.rows, stream=0)
+        plan.run([run.words, run.uaux[0]], params, run.rows, stream=0)
     c_ms = plan.kernel_ms()[0]
     plan.close()
     el = sorted(times)[len(times) // 2]
     slots = int(run.ns)
     # bytes the walk has to move: per pileup read one base + one quality in, the two plane words out; the alignment records
     # and CIGARs once per tile they touch (counted once here); umi_start and the descriptor per locus
-    need = 2.0 * run.reads + 8.0 * slots + 36.0 * len(run.A["aln"]) + 4.0 * run.A["cig"].nbytes / 4 + 36.0 * run.nl
+    need = 2.0 * run.reads + 4.0 * slots + 36.0 * len(run.A["aln"]) + 4.0 * run.A["cig"].nbytes / 4 + 36.0 * run.nl
     n = max(1, run.t["n"])
     # HBM bytes per launch of the walk from the committed PMC passes (profiles/traffic.json), over THIS run's kernel time
     traffic, traffic_src = None, None
@@ -169,7 +169,7 @@ def run_leg(eng, cfg_name: str, n_loci: int, steps: int, warmup: int, blocks: in
         "workload": "%s-shaped alignments: %d loci, %d alignments (%d barcodes, %d fragments), %d pileup reads, depth %.0f; "
                     "resident in HBM (%.2f GB)" % (cfg_name, run.nl, len(run.A["aln"]), run.A["n_bc"], run.A["n_pair"], run.reads,
                                                      run.reads / run.nl, run.input_bytes() / 1e9),
-        "step": "smc_build_planes -> smc_plan_create_dev (binning on the device) -> smc_plan_run -> rows in HBM",
+        "step": "smc_build_planes (read words) -> smc_plan_create_dev (binning on the device) -> smc_plan_run_words -> rows in HBM",
         "value": run.nl * steps / el, "unit": "loci/s", "ms_per_step": el / steps * 1e3,
         "blocks_ms_per_step": [round(t / steps * 1e3, 3) for t in times],
         "pileup_reads_per_s": run.reads * steps / el,
@@ -179,7 +179,7 @@ def run_leg(eng, cfg_name: str, n_loci: int, steps: int, warmup: int, blocks: in
                      "kernel_samples": k_n.value, "needed_bytes_per_launch": need,
                      "achieved": need / (k_ms.value * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": need / (k_ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "frac_basis": "needed bytes: 2 B in + 8 B out per pileup read, alignment records and CIGARs once",
+                     "frac_basis": "needed bytes: 2 B in + 4 B out (the read word) per pileup read, alignment records and CIGARs once",
                      "reads_per_s_kernel": run.reads / (k_ms.value * 1e-3), "traffic": traffic, "traffic_source": traffic_src},
         "builder_status": st,
         "generate_s": round(run.t_gen, 1),

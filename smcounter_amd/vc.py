@@ -51,12 +51,17 @@ def _strings(out_rows, db, params: VcParams, refprov) -> List[str]:
     return text
 
 
+def _kernel_planes(rb):
+    """What the kernels read of a resident batch: its read words + umi_start (else the raw-field planes, packed by the run)."""
+    return [rb.words, rb.planes[4]] if getattr(rb, "words", None) is not None else rb.planes
+
+
 def vc_resident(rb, params: VcParams, refprov, eng: _engine.Engine) -> List[str]:
     """`vc_batch` for a batch whose planes are already in HBM (devplanes.ResidentBatch: built there by smc_build_planes):
     plan, kernels, rows back, strings - no plane ever crosses PCIe."""
     plan = eng.make_plan(rb.loci)
     try:
-        out_rows = plan.run_devbuf(rb.planes, params)
+        out_rows = plan.run_devbuf(_kernel_planes(rb), params)
     finally:
         plan.close()
     eng.last_rows = out_rows                  # (the command line looks at them once more: rows.pi_boundary_loci)
@@ -68,7 +73,7 @@ def vc_resident_rows(rb, params: VcParams, eng: _engine.Engine):
     writing rank (packed) instead of strings."""
     plan = eng.make_plan(rb.loci)
     try:
-        return plan.run_devbuf(rb.planes, params).copy()
+        return plan.run_devbuf(_kernel_planes(rb), params).copy()
     finally:
         plan.close()
 

@@ -21,9 +21,12 @@ def _same_batch(rb, hb):
     same fragments and the same reads in the same order within a fragment, the same sampling marks and allele tables.  The two
     builders number the barcodes (and a barcode's fragments) of a locus differently - first appearance in the run vs at the
     locus, both within the layout contract - so the comparison is on the order-free fingerprint of planecheck.py."""
-    from smcounter_amd import planecheck
+    from smcounter_amd import devplanes, planecheck
     db = rb.to_host()
     assert planecheck.differences(db, hb) == []
+    # the read words (what the locus kernels load) say what the raw-field planes of the same build say
+    words = rb.words.download(np.uint32, rb.n_slots)
+    assert np.array_equal(words, devplanes.pack_words_host(db.meta, db.frag, db.loci))
     for l in range(db.n_loci):
         assert int(db.loci["umi_off"][l]) + int(db.loci["n_umi"][l]) + 1 <= len(db.umi_start)
 
@@ -210,8 +213,12 @@ def test_synthetic_alignments_through_the_device_builder_and_through_the_decoder
     got = vc.vc_resident(rb, P, fa, engine0)
     assert got == rows.format_rows(engine0.call_batch_host(hb, P), hb, P, fa)
     plan = engine0.make_plan(rb.loci)
-    dev_rows = plan.run_devbuf(rb.planes, P)
+    dev_rows = plan.run_devbuf(rb.planes, P).copy()                              # raw-field planes: smc_pack_words, then the kernels
+    assert plan.run_devbuf([rb.words, rb.planes[4]], P).tobytes() == dev_rows.tobytes()   # the builder's own read words
     plan.close()
+    # words only (what the command line builds): the same strings
+    rb1 = devplanes.resident_from_alignments(A, engine0, P, all_planes=False)
+    assert rb1.planes[0] is None and vc.vc_resident(rb1, P, fa, engine0) == got
     want, fragile, pi_all = oracle_lib.call_batch(hb, abi.c_params(P), abi.ROW_DTYPE, return_fragile=True, return_pi_all=True)
     assert abi.compare_rows(dev_rows, want, 1e-6, 1e-6, fragile, pi_all) == []
 
