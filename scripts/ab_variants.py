@@ -17,7 +17,8 @@ for path in libs:
     L = ctypes.CDLL(os.path.join(ROOT, "smcounter_amd", path))
     L.smc_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
     L.smc_plan_create.argtypes = [vp, vp, ctypes.c_int64, ctypes.POINTER(vp)]
-    L.smc_plan_run.argtypes = [vp, ctypes.POINTER(abi.SmcParams), vp, vp, vp, vp, vp, vp, vp]
+    L.smc_plan_run_words.argtypes = [vp, ctypes.POINTER(abi.SmcParams), vp, vp, vp, vp]
+    L.smc_pack_words.argtypes = [vp, vp, vp, vp, vp]
     L.smc_last_error.restype = ctypes.c_char_p
     ctx, plan = vp(), vp()
     assert L.smc_create(0, ctypes.byref(ctx)) == 0, L.smc_last_error()
@@ -26,9 +27,11 @@ for path in libs:
     H.append((path, L, plan))
 cp = abi.c_params(P)
 st = torch.cuda.current_stream()
+words = torch.empty_like(planes[0])
+assert H[0][1].smc_pack_words(H[0][2], planes[0].data_ptr(), planes[2].data_ptr(), words.data_ptr(), vp(st.cuda_stream)) == 0
+torch.cuda.synchronize()
 def run(L, plan):
-    rc = L.smc_plan_run(plan, ctypes.byref(cp), planes[0].data_ptr(), planes[1].data_ptr(), planes[2].data_ptr(),
-                        planes[3].data_ptr(), planes[4].data_ptr(), rows.data_ptr(), vp(st.cuda_stream))
+    rc = L.smc_plan_run_words(plan, ctypes.byref(cp), words.data_ptr(), planes[4].data_ptr(), rows.data_ptr(), vp(st.cuda_stream))
     assert rc == 0, L.smc_last_error()
 res = {p: [] for p, _, _ in H}
 ref = None
