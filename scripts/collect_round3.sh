@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything profiles/r03_* is assembled from, in one GPU call (every profiler run under its own timeout).
 # usage: bash scripts/collect_round3.sh   (writes gpurun_out/r03final/)
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03final; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r03final}; mkdir -p $O
 cd $R
 timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
 timeout 600 bash scripts/shapes_perf.sh 7 > $O/shapes.txt 2>&1
