@@ -319,6 +319,49 @@ def test_bad_ids_are_reported_not_crashed(engine0):
         rows.format_rows(got, db, P, synth.CyclicRef())
 
 
+def test_pack_words_matches_the_numpy_mirror_and_checks_the_slots(engine0):
+    """smc_pack_words (meta + frag planes -> one word per read) against devplanes.pack_words_host, the rows of smc_plan_run_words on those words against smc_plan_run on the planes - and the slot contract,
+    which only the packing step can see: a slot that steps by two, a first slot that is not 0, a last slot that is not
+    n_frag - 1 each flag their locus (class 31 in the word) and nobody else's."""
+    import torch
+    from smcounter_amd import devplanes
+    cfg = synth.CONFIGS["C2"]
+    P = synth.params_for(cfg)
+    db = synth.generate_native(cfg, 0, 64, P)
+    dev = torch.device("cuda", 0)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
+
+    def words_of(db):
+        plan = engine0.make_plan(db.loci)
+        meta, frag, ustart = up(db.meta), up(db.frag), up(db.umi_start)
+        words = torch.zeros_like(meta)
+        plan.pack_words(meta, frag, words)
+        r_words = plan.download(plan.run([words, ustart], P))
+        r_planes = plan.download(plan.run([meta, meta, frag, meta, ustart], P))
+        plan.close()
+        return words.cpu().numpy().view(np.uint32), r_words, r_planes
+
+    w, r_words, r_planes = words_of(db)
+    assert np.array_equal(w, devplanes.pack_words_host(db.meta, db.frag, db.loci))
+    assert r_words.tobytes() == r_planes.tobytes() and (r_words["status"] == 0).all()
+    for case in range(3):
+        bad = synth.generate_native(cfg, 0, 64, P)
+        o, n = bad.read_off(5), int(bad.loci["n_reads"][5])
+        slot = bad.frag[o:o + n] & np.uint32(features.FRAG_SLOT_MASK)
+        cls = bad.frag[o:o + n] & ~np.uint32(features.FRAG_SLOT_MASK)
+        if case == 0:
+            slot[n // 2:] += 1                                   # a step of two in the middle
+        elif case == 1:
+            slot += 1                                            # first slot 1
+        else:
+            bad.loci["n_frag"][5] += 1                           # last slot != n_frag - 1
+        bad.frag[o:o + n] = cls | slot
+        w, r_words, r_planes = words_of(bad)
+        assert r_words["status"][5] & abi.ST_BAD_INPUT and r_planes["status"][5] & abi.ST_BAD_INPUT
+        assert (np.delete(r_words["status"], 5) == 0).all()
+        assert ((w[o:o + n] >> 27) == 31).sum() >= 1
+
+
 def test_full_size_properties(engine0):
     """BASELINE.json's C2 at full size (10k loci) through size-independent properties: every locus
     reports DP = depth, UMT = barcodes, sum of per-allele depths <= DP, PI_ref ~ barcodes * PI of a
