@@ -152,12 +152,11 @@ static inline uint16_t smc_param_fingerprint(int32_t min_bq, int32_t min_mq, dou
  * n_frag = number of distinct fragments (= allFrag, smCounter.py:483).
  * umi_start[umi_off + u], u = 0..n_umi, is the index (relative to the locus) of barcode u's first read;
  * the last entry equals n_reads. Every barcode has at least one read. Given barcode-major reads, umi_start
- * determines the umi plane; the kernels use umi_start and the slot order and do not load the umi
- * plane. frag words carry the read class in bits 27-31 (smc_read_class above); with it the kernels do not load the
- * dist plane either: `umi` and `dist` may be NULL in smc_plan_run / smc_call_batch_host (they are the raw fields the
- * CPU restatement checks the classes and the order against). Checked per locus, violations flag the row
- * SMC_ST_BAD_INPUT: frag < n_frag, allele < n_alleles, umi_start ascending and covering [0, n_reads),
- * barcode slot ranges ascending and covering [0, n_frag).
+ * determines the umi plane; the kernels use umi_start and the fragment-start bit of the read words and load neither the umi
+ * plane nor - with the read class (smc_read_class above) - the dist plane: `umi` and `dist` may be NULL in smc_plan_run /
+ * smc_call_batch_host (they are the raw fields the CPU restatement checks the classes and the order against). Checked per
+ * locus, violations flag the row SMC_ST_BAD_INPUT: fragment slots dense and ascending, 0 .. n_frag - 1 (smc_pack_words),
+ * allele < n_alleles, a known read class, umi_start ascending and covering [0, n_reads), every barcode starting a fragment.
  * Base qualities are Phred values <= 126 (BAM holds 0..93); larger bytes are clamped to 126. */
 /* smc_locus.flags */
 #define SMC_LF_SAMPLED 1u /* the host has applied the reference's down-sampling (smCounter.py:496-498): barcodes whose

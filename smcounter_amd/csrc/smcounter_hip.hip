@@ -5,12 +5,14 @@
 //
 //   k_build_planes.inc   the planes of a run from its alignments (smCounter.py:316-366, :371-452, :462-471): the alignments of a
 //                        tile of 64 loci are radix-sorted ONCE by (barcode, fragment, file index); a wavefront (lane = locus)
-//                        then walks its part of that list - alignment record and CIGAR wave-uniform, the lane tests its own
-//                        position - first counting, then writing the plane words through an LDS staging buffer.
+//                        then takes its part of that list a batch at a time as bit COLUMNS (which alignments cover the lane's
+//                        locus; which of them start a fragment / a barcode there) - ranks are popcounts - first counting, then
+//                        writing ONE word per read through an LDS staging buffer.
 //   k_plan.inc           the launch plan of a batch whose descriptors are in HBM: class and weight bucket per locus, the launch
 //                        lists written on the device (smc_plan_create_dev).
 //   k_call_v2.inc        scan + group + score + rank, one workgroup per locus (several for a deep one).  The reads arrive
-//                        barcode-major with dense ascending fragment slots and a 5-bit read class, so nothing is looked up:
+//                        barcode-major, each word saying whether it starts a fragment and carrying a 5-bit read class, so
+//                        nothing is looked up:
 //                        the scan evaluates its predicates four reads at a time as byte lanes of one register (v_perm_b32,
 //                        DPP look-back), leaves ONE flag byte per read in LDS (fragment survives in bcDict / shows the reference
 //                        allele / merged pair / included / fragment start, :468-479), and counts alleleCnt (:379,401,459).
@@ -22,9 +24,11 @@
 //   k_filter_loci.inc    filterVariants minus the two FASTA-dependent flags (:182-269) for the loci on the worklist; Fisher
 //                        exact two-sided by chunked hypergeometric sums with a log-factorial table.
 //   k_pack_rows.inc      432-byte rows -> 168-byte wire rows for the multi-GPU gather.
+//   k_pack_words.inc     raw-field planes (meta, frag) -> read words, for batches a host builder made.
 //
-// Data layout (include/smcounter_hip.h): 16 B per pileup read in four uint32 planes, of which the locus
-// kernels read two (meta, frag) and umi_start; a 32-byte descriptor per locus; a 432-byte row out.
+// Data layout (include/smcounter_hip.h): ONE uint32 per pileup read (allele, quality, fragment start, read
+// class - what is left of the 16 B of raw fields per read once the plane builder has digested them) and umi_start; a 32-byte
+// descriptor per locus; a 432-byte row out.
 // This is integer / branchy, HBM-streaming work: no MFMA.
 #include <hip/hip_runtime.h>
 
