@@ -29,7 +29,7 @@ def needs_build() -> bool:
         return True
     t = os.path.getmtime(LIB)
     import glob
-    deps = [SRC, os.path.join(ROOT, "include", "smcounter_hip.h")] + glob.glob(os.path.join(HERE, "csrc", "*.inc"))
+    deps = [SRC, os.path.join(ROOT, "include", "smcounter_hip.h")] + glob.glob(os.path.join(HERE, "csrc", "*.inc")) + glob.glob(os.path.join(HERE, "csrc", "*.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -589,3 +589,38 @@ def test_loci_at_a_printing_boundary_are_reported():
         assert rows.pi_boundary_loci(got).tolist() == []
         n += len(got)
     assert n > 600
+
+
+def test_bp_heads_bit_trick_against_a_loop_over_the_rows(tmp_path):
+    """csrc/bp_masks.h: bp_heads - "the rows that start a run at this locus" by a segmented prefix OR on 32-bit masks, the centre of
+    the plane builder's walks (ranks, fragment starts and barcode numbers are popcounts of what it returns) - compiled for the
+    host and compared with the definition, row by row, on random columns, run structures and carries."""
+    import ctypes, subprocess
+    src = tmp_path / "h.cpp"
+    src.write_text('#include "bp_masks.h"\nextern "C" uint32_t heads(uint32_t C, uint32_t S, int carried) { return bp_heads(C, S, carried != 0); }\n')
+    lib = tmp_path / "h.so"
+    subprocess.check_call(["g++", "-O1", "-shared", "-fPIC", "-I", os.path.join(ROOT, "smcounter_amd", "csrc"), "-o", str(lib), str(src)])
+    L = ctypes.CDLL(str(lib))
+    L.heads.restype = ctypes.c_uint32
+    L.heads.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int]
+    rng = np.random.default_rng(5)
+
+    def want(C, S, carried):
+        H, seen = 0, bool(carried)                  # seen: a row of the current run has covered the locus already
+        for r in range(32):
+            if r and not (S >> r) & 1:
+                seen = False                        # row r starts a new run
+            if (C >> r) & 1:
+                if not seen:
+                    H |= 1 << r
+                seen = True
+        return H
+
+    cases = [(0, 0, 0), (0xFFFFFFFF, 0xFFFFFFFE, 0), (0xFFFFFFFF, 0xFFFFFFFE, 1), (0xFFFFFFFF, 0, 1), (0x80000001, 0xFFFFFFFE, 0)]
+    for _ in range(20000):
+        dens = rng.choice([0.05, 0.3, 0.7, 0.97])
+        C = int(rng.integers(0, 1 << 32)) & int(sum(1 << b for b in range(32) if rng.random() < rng.choice([0.3, 0.66, 1.0])))
+        S = int(sum(1 << b for b in range(1, 32) if rng.random() < dens))
+        cases.append((C, S, int(rng.integers(0, 2))))
+    for C, S, c in cases:
+        assert L.heads(C, S, c) == want(C, S, c), (hex(C), hex(S), c)
