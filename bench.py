@@ -146,6 +146,9 @@ def roofline_block(plan_loci, k_ms, k_n, k_loci, k_reads, cfg_key):
             "traffic": traffic, "traffic_source": src,
             "kernel_ms": k_ms, "kernel_samples": k_n, "loci_per_launch": k_loci,
             "needed_bytes_per_launch": need, "hbm_bytes_per_launch_pmc": traffic_bytes,
+            # the same launch charged the 8 B per read slot it moved until round 3 (meta + frag words): for comparison with
+            # earlier rounds' `frac` only - the kernel no longer moves those bytes
+            "frac_on_round2_bytes": (need + 4.0 * float(((plan_loci["n_reads"].astype("int64") + 3) // 4 * 4).sum())) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "alg_bytes_per_launch_survey_8d": alg_bytes, "achieved_survey_8d": alg_bytes / (k_ms * 1e-3) / 1e9,
             "frac_survey_8d": alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "note": "frac_survey_8d counts SURVEY 8d's 16 B/read (four raw-field planes); the kernels load 4 B/read - the read word "
