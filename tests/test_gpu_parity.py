@@ -203,6 +203,32 @@ def test_general_path_with_and_without_the_reference_fragment_shortcut(monkeypat
     eng.close()
 
 
+def test_one_allele_barcodes_of_the_major_other_allele(monkeypatch):
+    """Deep loci (> 24576 reads) guess their major other allele from 64 sampled reads and score the barcodes whose live fragments
+    all show it from the per-count table, like the reference allele's (calProb's posteriors of a one-allele barcode depend on the
+    fragment count only).  With the shortcut (default) and without (SMC_NO_ALT=1): every integer column equal, PI far inside the
+    tolerance - on the example run's shape (58 k reads, 30 % of the loci with a variant: the shortcut is taken) and on a deep
+    shape without variants; both against the CPU restatement.  Shallow loci are not touched by it at all."""
+    from smcounter_amd import engine
+    eng = engine.Engine(0)
+    for name, n, taken in (("EX", 40, True), ("X9", 24, None), ("C3", 300, False)):
+        cfg = synth.CONFIGS[name]
+        P = synth.params_for(cfg)
+        db = synth.generate_native(cfg, 0, n, P)
+        alt = eng.call_batch_host(db, P)
+        monkeypatch.setenv("SMC_NO_ALT", "1")
+        full = eng.call_batch_host(db, P)
+        monkeypatch.delenv("SMC_NO_ALT")
+        if taken is True:
+            assert alt.tobytes() != full.tobytes(), name          # (the shortcut was taken)
+        elif taken is False:
+            assert alt.tobytes() == full.tobytes(), name
+        assert abi.compare_rows(alt, full, 1e-9, 1e-12) == [], name
+        want, fragile = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE, return_fragile=True)
+        assert abi.compare_rows(alt, want, PI_TOL, P_TOL, fragile) == [], name
+    eng.close()
+
+
 def test_locus_above_2_to_18_reads(engine0):
     """312,000 reads on one locus (the kernel takes up to 2^24; pysam's max_depth in the reference is 10^6): 22 parts,
     rows equal to the CPU restatement."""
