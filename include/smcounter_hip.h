@@ -87,10 +87,15 @@ extern "C" {
 /* The read word: what the locus kernels read, ONE uint32 per read (4 of the raw-field planes' 16 bytes cross HBM).
  *   bits 0-7 allele id, 8-15 base quality (<= 126; minBQ for a read inside a deletion) - the low half of the meta word;
  *   bit 16 the read is the first of its fragment at this locus (the fragment slots are dense and ascending, so the slot
- *          number itself carries nothing else); bits 17-26 zero; bits 27-31 the read class (as in the frag word).
+ *          number itself carries nothing else); bit 17 the read is included (incCond, smCounter.py:378) and bit 18 its class is
+ *          one of the SMC_N_READ_CLASS known ones - both functions of the class (smc_class_bits below), spelled out so that the
+ *          scan takes them with the fragment bit in one byte instead of looking the class up; bits 19-26 zero; bits 27-31 the
+ *          read class (as in the frag word).
  * smc_build_planes writes it directly; smc_pack_words folds a batch's meta and frag planes into it (and checks the slot
  * contract, which the words can no longer break); smc_plan_run_words runs on it. */
 #define SMC_RW_NF 0x00010000u
+#define SMC_RW_INC 0x00020000u
+#define SMC_RW_OK 0x00040000u
 #define SMC_RW_CLASS_SHIFT 27
 #if defined(__HIPCC__)
 #define SMC_HOST_DEVICE __host__ __device__   /* (the device plane builder evaluates it too) */
@@ -105,6 +110,13 @@ SMC_HOST_DEVICE static inline uint32_t smc_read_class(int kind, int rev, int r2,
     else if (!r2) sub = 2u + (le20 ? 1u : 0u);
     else sub = 4u + (le20 ? 1u : 0u) + (prle ? 2u : 0u);
     return 6u + (rev ? 8u : 0u) + sub;
+}
+
+/* bits 17-18 of the read word for a class: included = the incCond half of smc_read_class's encoding, known = class < 22 */
+SMC_HOST_DEVICE static inline uint32_t smc_class_bits(uint32_t cls) {
+    if (cls >= SMC_N_READ_CLASS) return 0u;
+    const int inc = cls < 6u ? (int)(cls & 1u) : (((cls - 6u) & 7u) >= 2u);
+    return SMC_RW_OK | (inc ? SMC_RW_INC : 0u);
 }
 
 /* The numeric arguments vc() receives (smCounter.py:274) that the device path needs, plus the two

@@ -73,7 +73,12 @@ def pack_words_host(meta: np.ndarray, frag: np.ndarray, loci: np.ndarray) -> np.
     np.add.at(d, start, 1)
     np.add.at(d, start + n, -1)
     valid = np.cumsum(d[:-1]) > 0
-    w = (meta & np.uint32(0xFFFF)) | (nf.astype(np.uint32) << np.uint32(16)) | ((frag >> np.uint32(FRAG_CLASS_SHIFT)) << np.uint32(27))
+    cls = frag >> np.uint32(FRAG_CLASS_SHIFT)
+    # bits 17 / 18: the read is included / its class is a known one (include/smcounter_hip.h: smc_class_bits)
+    c = np.arange(32)
+    inc = np.where(c < 6, c & 1, ((c - 6) & 7) >= 2).astype(np.uint32)
+    bits = np.where(c < 22, (np.uint32(4) | inc << np.uint32(1)), np.uint32(0)).astype(np.uint32) << np.uint32(16)
+    w = (meta & np.uint32(0xFFFF)) | (nf.astype(np.uint32) << np.uint32(16)) | bits[cls] | (cls << np.uint32(27))
     return np.where(valid, w, np.uint32(0)).astype(np.uint32)
 
 
