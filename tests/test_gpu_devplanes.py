@@ -146,6 +146,51 @@ def test_loci_deeper_than_the_on_chip_sort(engine0, tmp_path, depth):
     _same_batch(rb, hb)
 
 
+def test_a_tile_with_hundreds_of_distinct_indel_alleles(engine0, tmp_path):
+    """More distinct extra alleles in one 64-locus tile than k_bp_xfix's report buffer holds (256): the surplus reports take the
+    one-by-one path.  Every locus of the tile sees several insertions of different sequences and lengths and a few deletions;
+    the allele tables, the numbering by first appearance and the planes must equal the host builder's."""
+    from smcounter_amd import devplanes
+    rng = np.random.default_rng(11)
+    L = 300
+    ref = "".join(rng.choice(list("ACGT"), size=L))
+    fa_path = str(tmp_path / "x.fa")
+    open(fa_path, "w").write(">chrX\n" + ref + "\n")
+    recs = []
+    i = 0
+    for at in range(70, 140):                                   # an insertion / deletion right behind reference position `at`
+        for v in range(7):
+            start = at - 20 - int(rng.integers(0, 10))
+            left = at + 1 - start
+            if v < 5:
+                ins = "".join(rng.choice(list("ACGT"), size=1 + v))
+                cigar = [(0, left), (1, len(ins)), (0, 30)]
+                seq = ref[start:start + left] + ins + ref[start + left:start + left + 30]
+            else:
+                dl = 1 + (v - 5)
+                cigar = [(0, left), (2, dl), (0, 30)]
+                seq = ref[start:start + left] + ref[start + left + dl:start + left + dl + 30]
+            for mate in (0, 1):
+                recs.append(dict(tid=0, pos=start, qname="r%d:x:BC%03d:y" % (i, int(rng.integers(0, 40))), flag=(0x41 if mate == 0 else 0x91),
+                                 mapq=60, cigar=cigar, seq=seq, qual=[30] * len(seq), nm=1))
+            i += 1
+    recs.sort(key=lambda r: r["pos"])
+    bam = str(tmp_path / "x.bam")
+    bamio.write_bam(bam, [("chrX", L)], recs)
+    bamio.write_bai(bam)
+    fa = fasta.FastaFile(fa_path)
+    loci = [("chrX", str(p)) for p in range(65, 65 + 128)]
+    P = VcParams(mtDepth=1000, rpb=2.0, hpLen=8)
+    host = list(bamio.iter_device_batches_native(bam, fa, loci, P))
+    dev = list(devplanes.iter_resident_batches(bam, fa, loci, P, engine0))
+    assert len(host) == len(dev) == 1
+    (_, hb), (_, rb) = host[0], dev[0]
+    assert rb.n_device_runs >= 1 and rb.n_host_runs == 0
+    per_tile = [sum(len(t) - 6 for t in hb.alleles[k:k + 64]) for k in range(0, hb.n_loci, 64)]
+    assert max(per_tile) > 256, per_tile                        # (the buffer really overflows)
+    _same_batch(rb, hb)
+
+
 def test_targets_out_of_order_and_scattered(engine0, tmp_path):
     """Targets visited out of coordinate order, single scattered positions among them (every stretch of consecutive positions
     is a run of its own; the decoder's cursor has to go back): same batches as the host builder."""
