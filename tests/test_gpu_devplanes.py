@@ -146,6 +146,43 @@ def test_loci_deeper_than_the_on_chip_sort(engine0, tmp_path, depth):
     _same_batch(rb, hb)
 
 
+def test_small_and_large_sort_segments_in_one_run(engine0, tmp_path):
+    """A run of more than 512 loci whose first 512-locus segment holds a few hundred alignments (sorted by one workgroup,
+    k_bp_sort_seg) and whose second has a tile beyond 16,384 (k_bp_hist / k_bp_scan / k_bp_scatter): the multi-launch passes
+    have to put their output behind EVERY earlier segment, not only behind the earlier multi-launch ones."""
+    from smcounter_amd import devplanes
+    rng = np.random.default_rng(512)
+    L = 1100
+    ref = "".join(rng.choice(list("ACGT"), size=L))
+    fa_path = str(tmp_path / "mix.fa")
+    open(fa_path, "w").write(">chrS\n" + ref + "\n")
+    recs = []
+    for i in range(9400):
+        deep = i >= 400
+        start = 700 + int(rng.integers(0, 6)) if deep else int(rng.integers(20, 1000))
+        bc = int(rng.integers(0, 700))
+        for mate in (0, 1):
+            pos = start + (0 if mate == 0 else int(rng.integers(0, 8)))
+            cigar = [(0, 60)] if rng.random() > 0.03 else [(0, 20), (1, 2), (0, 38)]
+            seq = ref[pos:pos + 60]
+            recs.append(dict(tid=0, pos=pos, qname="r%d:x:BC%04d:y" % (i, bc), flag=(0x41 if mate == 0 else 0x91), mapq=60,
+                             cigar=cigar, seq=seq, qual=rng.choice([12, 25, 30, 37], size=60).astype(np.uint8).tolist(), nm=0))
+    recs.sort(key=lambda r: r["pos"])
+    bam = str(tmp_path / "mix.bam")
+    bamio.write_bam(bam, [("chrS", L)], recs)
+    bamio.write_bai(bam)
+    fa = fasta.FastaFile(fa_path)
+    loci = [("chrS", str(p)) for p in range(40, 900)]
+    P = VcParams(mtDepth=100000, rpb=2.0, hpLen=8)
+    host = list(bamio.iter_device_batches_native(bam, fa, loci, P, max_reads=64_000_000))
+    dev = list(devplanes.iter_resident_batches(bam, fa, loci, P, engine0, max_reads=64_000_000))
+    assert len(host) == len(dev) == 1
+    (_, hb), (_, rb) = host[0], dev[0]
+    assert int(hb.loci["n_reads"].max()) > 16384 and int(hb.loci["n_reads"][:512].max()) < 200
+    assert rb.n_device_runs >= 1 and rb.n_host_runs == 0
+    _same_batch(rb, hb)
+
+
 def test_a_tile_with_hundreds_of_distinct_indel_alleles(engine0, tmp_path):
     """More distinct extra alleles in one 64-locus tile than k_bp_xfix's report buffer holds (256): the surplus reports take the
     one-by-one path.  Every locus of the tile sees several insertions of different sequences and lengths and a few deletions;
