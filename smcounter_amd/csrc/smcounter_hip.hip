@@ -54,6 +54,7 @@
 // One translation unit; the parts:
 #include "device_common.inc"   // LDS header, DPP reductions, encodings, k_simple_table, finish_row (E stage)
 #include "k_build_planes.inc" // kernel 0: the planes from a run's alignments (device half of the feature extraction)
+#include "k_bp_emit2.inc"     //   its walk that writes the planes (lane = alignment)
 #include "k_call_v2.inc"       // kernel 1: scan + group + score + rank (whole loci; deep loci in parts and chunks)
 #include "k_filter_loci.inc"   // kernel 2: filterVariants / Fisher exact for the loci on the worklist
 #include "k_pack_rows.inc"     // kernel 3: rows -> 168-byte wire rows for the multi-GPU gather
