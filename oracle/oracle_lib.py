@@ -102,3 +102,64 @@ def fisher(a, b, c, d):
     lib().smc_oracle_fisher(ctypes.c_int64(a), ctypes.c_int64(b), ctypes.c_int64(c), ctypes.c_int64(d),
                             ctypes.byref(o), ctypes.byref(p))
     return o.value, p.value
+
+
+_ALN = None
+
+
+def aln_planes(A, params, l0=0, l1=None, n_threads=1):
+    """oracle/aln_planes.c: the raw-field planes of loci [l0, l1) of a run of alignments (the dict synth.generate_alignments /
+    the decoder make: aln, cig, seq, qual, loc, start0, nl), built the reference's way on the host cores -> a DeviceBatch
+    (its string context - chromosome, reference letters, allele texts - left for the caller to fill where it prints)."""
+    global _ALN
+    import threading
+    from smcounter_amd import features, synth
+    if _ALN is None:
+        path = os.path.join(HERE, "libaln_planes.so")
+        if not os.path.exists(path):
+            build()
+        _ALN = ctypes.CDLL(path)
+        _ALN.smc_aln_planes.restype = ctypes.c_int
+    l1 = int(A["nl"]) if l1 is None else int(l1)
+    l0 = int(l0)
+    loc = np.ascontiguousarray(A["loc"])
+    s0 = int(loc["slot_off"][l0])
+    s1 = int(loc["slot_off"][l1 - 1]) + ((int(loc["n"][l1 - 1]) + 3) // 4 * 4)
+    n_slots, nl = s1 - s0, l1 - l0
+    planes = [np.zeros(n_slots, np.uint32) for _ in range(4)]
+    umi_start = np.zeros(n_slots + nl + 1, np.uint32)
+    loci = np.zeros(int(A["nl"]), features.LOCUS_DTYPE)
+    lo = int(A["start0"])
+    refseq = np.frombuffer(A["refseq"] if "refseq" in A else synth.aln_ref_fetch(lo, lo + int(A["nl"])).encode(), np.uint8)
+    fp = features.param_fingerprint(params)
+    vp = ctypes.c_void_p
+    # slot_base / umi_base such that locus l0 starts at slot 0 / entry 0 (modulo 2^32, as the C side computes them)
+    slot_base = (-s0) & 0xFFFFFFFF
+    umi_base = (-(s0 + l0)) & 0xFFFFFFFF
+    errs = []
+    n_threads = max(1, min(int(n_threads), nl))
+    bounds = [l0 + nl * t // n_threads for t in range(n_threads + 1)]
+    arrs = [np.ascontiguousarray(A[k]) for k in ("aln", "cig", "seq", "qual")]
+
+    def work(a, b):
+        if b <= a:
+            return
+        rc = _ALN.smc_aln_planes(vp(arrs[0].ctypes.data), vp(arrs[1].ctypes.data), vp(arrs[2].ctypes.data), vp(arrs[3].ctypes.data),
+                                 vp(loc.ctypes.data), vp(refseq.ctypes.data), ctypes.c_int32(lo), ctypes.c_int32(a), ctypes.c_int32(b),
+                                 ctypes.c_int32(params.minBQ), ctypes.c_int32(params.minMQ), ctypes.c_int32(params.primerDist),
+                                 ctypes.c_uint32(fp), ctypes.c_uint32(slot_base), ctypes.c_uint32(umi_base),
+                                 vp(planes[0].ctypes.data), vp(planes[1].ctypes.data), vp(planes[2].ctypes.data), vp(planes[3].ctypes.data),
+                                 vp(umi_start.ctypes.data), vp(loci.ctypes.data))
+        if rc != 0:
+            errs.append(rc)
+    th = [threading.Thread(target=work, args=(bounds[t], bounds[t + 1])) for t in range(n_threads)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if errs:
+        raise RuntimeError("smc_aln_planes failed: %r" % errs)
+    pos = np.arange(lo + l0 + 1, lo + l1 + 1, dtype=np.int64)
+    return features.DeviceBatch(loci=loci[l0:l1].copy(), meta=planes[0], umi=planes[1], frag=planes[2], dist=planes[3],
+                                umi_start=umi_start, chrom=[synth.ALN_CHROM] * nl, pos=pos,
+                                ref=[chr(c) for c in refseq[l0:l1]], alleles=[[] for _ in range(nl)])
