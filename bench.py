@@ -1,38 +1,39 @@
 #!/usr/bin/env python3
 """bench.py - throughput of the per-locus hot path on synthetic pileups of stated depth.
 
-Metric (BASELINE.json): loci/s at fixed read-depth x reads-per-UMI.  Workload at every N:
-BASELINE.json configs[2] "synthetic 200k loci, 3000x depth, 50 UMIs/locus, 60 rpb" PER GPU (weak
-scaling: rank r calls loci [r*200k, (r+1)*200k) of the same seeded config), inputs resident in HBM
-before the timed region.  A step = one pass of the hot path (k_call_v2 bins + k_filter_loci) over
-the rank's batch, followed, for N > 1, by the gather of the rows to rank 0 (RCCL; the gather of a step
-overlaps the next step's kernels, two row buffers per rank - every step's rows are gathered inside the
-timed region).  `--scaling strong --config C4`: BASELINE's configs[3], 1 M loci IN TOTAL sharded over
-the ranks (it fits one MI355X as well: the N = 1 anchor of that curve).
+Metric (BASELINE.json): loci/s at fixed read-depth x reads-per-UMI.  Workload at every N: BASELINE.json configs[2]
+"synthetic 200k loci, 3000x depth, 50 UMIs/locus, 60 rpb" PER GPU (weak scaling: rank r takes its own stretch of the seeded
+config), inputs resident in HBM before the timed region.
 
-The timed region is a block of EXACTLY --steps steps between barrier + synchronize on both sides; the
-block is repeated --blocks times (default 5) and `value` / `ms_per_step` come from the MEDIAN block
-(every block's ms_per_step is listed under `blocks`): one 20-step block is ~30 ms, too short to trust
-to a percent.
+A STEP is the whole device path from where the reference's hot loop starts (smCounter.py:316, the pileup over the alignments):
+the run's ALIGNMENTS (what the BAM decoder hands over: one record per alignment, CIGARs, bases, qualities; ~ 1.4 GB for C3) ->
+smc_build_planes (the per-pileup-read work of vc(): sort, count, the walk that writes one word per read) -> smc_plan_create_dev ->
+smc_plan_run_words (k_call_v2 bins + k_filter_loci) -> rows in HBM; for N > 1 followed by the gather of the packed rows to rank 0
+(RCCL; the gather of a step overlaps the next step's kernels, two row buffers per rank - every step's rows are gathered inside the
+timed region).  `--scaling strong --config C4`: BASELINE's configs[3], 1 M loci IN TOTAL sharded over the ranks.
+(Rounds 1-3 quoted `value` on the second half of that path alone - the locus kernels over read words already resident; that
+figure is kept as `consumer_only`.)
 
-Prints ONE JSON line on rank 0 (see the task contract): value = loci of all ranks / max-over-ranks
-time; roofline = the bytes the dominant kernel has to move per launch over its mean HIP-event duration,
-against 8 TB/s (`frac`, with `frac_basis`; SURVEY.md 8d's 16 B/read figure beside it as
-`frac_survey_8d`); cpu_baseline = CPU legs timed on a bounded sample of the same workload (rank 0,
-N = 1 only; physical cores stated, the single-process rate beside the pool's); parity = EVERY row of the
-run against the CPU restatement with the number of loci whose order-dependent fields were excused, the
-loci that reached filterVariants, the Fisher tests run and the largest p-value difference;
-other_configs = the other single-GPU shapes (C2, C5, X3 - 30 % of the loci with a candidate -, EX - the
-statistics of the reference's own example run), each timed the same way in the same process;
-from_alignments = the same C3 depth shape timed from where the reference's hot loop starts
-(smCounter.py:316): alignments resident in HBM -> plane builder -> launch plan -> hot path
-(smcounter_amd/fa_leg.py), with the plane-writing kernel's own roofline.
+`python3 bench.py --gpus N` without a launcher starts its own ranks: a child `python -m torch.distributed.run --nnodes 1
+--nproc-per-node N bench.py <same arguments>`, rank 0's JSON line relayed, the child's exit code returned.
+
+The timed region is a block of EXACTLY --steps steps between barrier + synchronize on both sides; the block is repeated
+--blocks times (default 5) and `value` / `ms_per_step` come from the MEDIAN block (all are listed under `blocks`).
+
+Prints ONE JSON line on rank 0: value = loci of all ranks / max-over-ranks time; roofline = the bytes the step's dominant kernel
+(the walk that writes the read words) has to move per launch over its mean HIP-event duration, against 8 TB/s; cpu_baseline =
+CPU legs timed on a bounded sample of the same workload (rank 0, N = 1 only; inputs made before the clock starts); parity = EVERY
+row of the run against the CPU (oracle/aln_planes.c + oracle/smc_oracle.c from the same alignments), with the number of loci
+whose order-dependent fields were excused, the loci that reached filterVariants, the Fisher tests run and the largest p-value
+difference; consumer_only = the locus kernels alone over resident read words (C3) and other_configs = the other single-GPU shapes
+that way (C2, C5, X3 - 30 % of the loci with a candidate -, EX - the statistics of the reference's own example run).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -43,8 +44,57 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps each; value = the median block")
+    ap.add_argument("--config", default="C3", help="synthetic config (C2, C3, C5, C4); C3 is the metric's")
+    ap.add_argument("--loci-per-gpu", type=int, default=0, help="override (default: the config's size)")
+    ap.add_argument("--chunk", type=int, default=25000, help="loci generated / checked per chunk")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the every-row checks against the CPU")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip consumer_only and the C2 / C5 / X3 / EX one-liners")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: the config's loci PER GPU (default, the driver's scaling run); strong: the config's loci in total, "
+                         "sharded over the ranks (e.g. --config C4: 1 M loci; fits one MI355X too)")
+    ap.add_argument("--rows", choices=("gather", "resident"), default="gather",
+                    help="N > 1: gather every step's rows to rank 0 (default; overlapped with the next step) or leave "
+                         "them in each rank's HBM (diagnostic: isolates the collective)")
+    ap.add_argument("--wire", choices=("packed", "full"), default="packed",
+                    help="N > 1: what travels to rank 0 - the packed wire rows (default) or the full 432-byte rows")
+    return ap.parse_args(argv)
+
+
+def self_launch(a) -> int:
+    """--gpus N without WORLD_SIZE: start the ranks as a CHILD process (never re-exec a process that may touch the GPU), relay
+    rank 0's JSON line, return the child's exit code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in proc.stdout:
+        if ln.lstrip().startswith("{") and '"metric"' in ln:
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 1
+    return rc
+
+
 def needed_bytes(loci) -> float:
-    """HBM bytes one launch of the hot path has to move for these loci: the read words (one uint32 per read slot: allele,
+    """HBM bytes one launch of the locus kernels has to move for these loci: the read words (one uint32 per read slot: allele,
     quality, fragment start, class), umi_start, the 32-byte descriptor + 4-byte launch-order entry, and the row written."""
     import numpy as np
     from smcounter_amd import abi
@@ -53,9 +103,9 @@ def needed_bytes(loci) -> float:
 
 
 class Resident(object):
-    """One config's batch resident in HBM: what the kernels read - the read words (packed on the device from the synthetic
-    batch's meta and frag planes, smc_pack_words, before anything is timed) and umi_start - + the plan; optionally the CPU
-    restatement's rows of every chunk (all host cores), kept for the parity pass."""
+    """One config's batch of READ WORDS resident in HBM (packed on the device from the synthetic batch's meta and frag planes
+    before anything is timed) and umi_start, + the plan: the input of the locus kernels alone (`consumer_only`,
+    `other_configs`); optionally the CPU restatement's rows of every chunk (all host cores), kept for the parity pass."""
 
     def __init__(self, eng, cfg, params, lo, hi, chunk, nthreads, dev, oracle=None):
         import numpy as np
@@ -96,7 +146,6 @@ class Resident(object):
         return self.plan.run(self.planes, self.params, rows)
 
     def parity(self, rows):
-        import numpy as np
         from smcounter_amd import abi
         got = self.plan.download(rows)
         tot = {"loci": 0, "mismatches": 0, "fragile_skipped": 0, "near_tie_skipped": 0, "pi_max_abs_diff": 0.0, "loci_filtered": 0,
@@ -121,38 +170,21 @@ class Resident(object):
         self.words = self.umi_start = self.planes = None
 
 
-def roofline_block(plan_loci, k_ms, k_n, k_loci, k_reads, cfg_key):
-    """`achieved` / `frac`: the bytes the dominant kernel HAS to move per launch (the read words - 4 B per read slot -,
-    umi_start, descriptors, rows) over its mean HIP-event duration, against the 8 TB/s peak.  SURVEY.md 8d's algorithmic figure
-    (16 B per read + 360 B per locus: the four raw-field planes of the layout, which the plane builder digests into the one
-    word per read the kernels load) is kept beside it as achieved_survey_8d / frac_survey_8d; it can exceed what a copy
-    achieves on this part and is not a fraction of anything the kernel does."""
-    alg_bytes = 16.0 * k_reads + 360.0 * k_loci              # per launch of the dominant kernel (SURVEY 8d)
+def call_roofline(plan_loci, k_ms, k_n, k_loci, k_reads, cfg_key):
+    """k_call_v2 alone: the bytes it HAS to move per launch (the read words - 4 B per read slot -, umi_start, descriptors, rows)
+    over its mean HIP-event duration, against the 8 TB/s peak.  SURVEY.md 8d's figure (16 B per read + 360 B per locus: the
+    four raw-field planes, which the plane builder digests into the one word per read the kernels load) is kept beside it; it
+    is not a fraction of anything this kernel does."""
+    import bench_fa
+    alg_bytes = 16.0 * k_reads + 360.0 * k_loci
     need = needed_bytes(plan_loci)
     achieved = need / (k_ms * 1e-3) / 1e9
-    # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), expressed like `achieved`:
-    # GB/s over THIS run's measured kernel duration.  A constant read from the committed profile, not measured here.
-    traffic, traffic_bytes, src = None, None, None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        rec = json.load(open(tpath)).get(cfg_key)
-        if rec:
-            traffic_bytes = rec["hbm_bytes_per_launch"]
-            traffic = traffic_bytes / (k_ms * 1e-3) / 1e9
-            src = "profiles/traffic.json <- " + rec.get("source", "rocprofv3 --pmc")
-    return {"bound": "hbm", "kernel": "k_call_v2", "achieved": achieved, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+    rec = bench_fa.traffic_record(cfg_key)
+    return {"kernel": "k_call_v2", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "frac_basis": "needed bytes per launch (4 B per read slot: the read word; + umi_start + descriptor + row) / kernel time / 8 TB/s",
-            "traffic": traffic, "traffic_source": src,
-            "kernel_ms": k_ms, "kernel_samples": k_n, "loci_per_launch": k_loci,
-            "needed_bytes_per_launch": need, "hbm_bytes_per_launch_pmc": traffic_bytes,
-            # the same launch charged the 8 B per read slot it moved until round 3 (meta + frag words): for comparison with
-            # earlier rounds' `frac` only - the kernel no longer moves those bytes
-            "frac_on_round2_bytes": (need + 4.0 * float(((plan_loci["n_reads"].astype("int64") + 3) // 4 * 4).sum())) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "alg_bytes_per_launch_survey_8d": alg_bytes, "achieved_survey_8d": alg_bytes / (k_ms * 1e-3) / 1e9,
-            "frac_survey_8d": alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "note": "frac_survey_8d counts SURVEY 8d's 16 B/read (four raw-field planes); the kernels load 4 B/read - the read word "
-                    "the plane builder folds them into (the from_alignments leg times it; rounds 1-3 loaded 8 B/read: meta + frag)"}
+            "traffic": rec["hbm_bytes_per_launch"] / (k_ms * 1e-3) / 1e9 if rec else None, "traffic_measured_in_run": False,
+            "kernel_ms": k_ms, "kernel_samples": k_n, "loci_per_launch": k_loci, "needed_bytes_per_launch": need,
+            "achieved_survey_8d": alg_bytes / (k_ms * 1e-3) / 1e9, "frac_survey_8d": alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
 def physical_cores():
@@ -174,45 +206,55 @@ def physical_cores():
         return os.cpu_count() or 1
 
 
+def dry_main(a, rank, world):
+    """SMC_BENCH_DRY=1: the launch plumbing without a GPU (CPU test of `--gpus N`): the ranks meet over gloo, run the timed
+    loop's barriers and the row gather on dummy rows, rank 0 prints the line (value null)."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+    rows = torch.full((64, 42), float(rank))
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        if world > 1:
+            got = [torch.empty_like(rows) for _ in range(world)] if rank == 0 else None
+            dist.gather(rows, got, dst=0)
+            if rank == 0:
+                assert all(float(g[0, 0]) == r for r, g in enumerate(got))
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps({"metric": "loci/sec at fixed read-depth x rpb", "value": None, "unit": "loci/s", "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / max(1, a.steps) * 1e3, "higher_is_better": True,
+                          "scaling": a.scaling, "vs_baseline": None, "dtype": "u8/u32 scan + f64 posterior", "data": "synthetic",
+                          "config": {"workload": "dry run: launch plumbing only (SMC_BENCH_DRY=1), no GPU work"}, "dry_run": True}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     global np, torch, dist, abi, engine, synth, smcdist
-    import numpy as np
-    from smcounter_amd import abi, synth
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps each; value = the median block")
-    ap.add_argument("--config", default="C3", help="synthetic config (C2, C3, C5); C3 is the metric's")
-    ap.add_argument("--loci-per-gpu", type=int, default=0, help="override (default: the config's size)")
-    ap.add_argument("--chunk", type=int, default=25000, help="loci generated/uploaded per chunk")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-parity", action="store_true", help="skip the every-row check against the CPU restatement")
-    ap.add_argument("--no-other-configs", action="store_true", help="skip the C2 / C5 / X3 / EX one-liners")
-    ap.add_argument("--no-from-alignments", action="store_true", help="skip the leg that starts from alignments (plane builder + hot path)")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="weak: the config's loci PER GPU (default, the driver's scaling run); strong: the config's loci in total, "
-                         "sharded over the ranks (e.g. --config C4: 1 M loci; fits one MI355X too)")
-    ap.add_argument("--rows", choices=("gather", "resident"), default="gather",
-                    help="N > 1: gather every step's rows to rank 0 (default; overlapped with the next step) or leave "
-                         "them in each rank's HBM (diagnostic: isolates the collective)")
-    ap.add_argument("--wire", choices=("packed", "full"), default="packed",
-                    help="N > 1: what travels to rank 0 - the packed wire rows (default) or the full 432-byte rows")
-    a = ap.parse_args()
-
+    a = parse_args()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(self_launch(a))               # (before anything here imports torch or touches a GPU)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)"
-                         % (a.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if os.environ.get("SMC_BENCH_DRY"):
+        return dry_main(a, rank, world)
+    import numpy as np
+    from smcounter_amd import abi, synth
     # The CPU leg runs FIRST, before this process touches the GPU: it starts worker processes.
     cpu = None
     if world == 1 and not a.no_cpu_baseline:
         cpu = cpu_leg(a)
     import torch
     import torch.distributed as dist
-    from smcounter_amd import engine
+    import bench_fa
+    from smcounter_amd import _lib, engine
     from smcounter_amd import dist as smcdist
     # (SMC_BENCH_SHARE_GPU=1: every rank on GPU 0 with the gloo backend - a FUNCTIONAL check of the N > 1 path on a box with
     # one GPU, where RCCL refuses two ranks on a device; its numbers are not a measurement of anything)
@@ -236,47 +278,49 @@ def main():
     lo, hi = smcdist.shard_range(total_loci, rank, world)         # contiguous, equal shares of the ordered locus list
     n_mine = hi - lo
     eng = engine.Engine(local_rank)
+    L = eng.L
     dev = torch.device("cuda", local_rank)
-    oracle = None
-    if world == 1 and not a.no_parity:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import oracle_lib as oracle
-
-    # ---- build the rank's batch in HBM, chunk by chunk (host RAM stays bounded)
-    t0 = time.time()
     nthreads = max(1, len(os.sched_getaffinity(0)) // max(1, world))
-    res = Resident(eng, cfg, params, lo, hi, a.chunk, nthreads, dev, oracle)
-    plan = res.plan
-    rows = plan.alloc_rows()
+
+    # ---- the rank's run of alignments, resident in HBM
+    t0 = time.time()
+    run = bench_fa.AlignmentRun(eng, cfg, params, n_mine, nthreads, shard=rank)
     torch.cuda.synchronize()
     t_build = time.time() - t0
+    rows = torch.empty(n_mine * abi.ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev)
 
     # N > 1: the rows of step i travel to rank 0 (RCCL, its own stream) while step i + 1 computes - two buffers per rank,
     # a buffer is reused only after its gather has completed (dist.RowPipeline).  What travels is the packed wire row
-    # (smc_pack_rows: every printed column, a third of the bytes) unless --wire full.
+    # (smc_pack_rows: every printed column, 168 of the 432 bytes) unless --wire full.
     gather = use_dist and a.rows == "gather"
     packed = gather and a.wire == "packed"
+    wire_bytes = L.smc_wire_row_size()
     if packed:
-        wires = [plan.alloc_wire(), plan.alloc_wire()]
+        wires = [torch.empty(n_mine * wire_bytes, dtype=torch.uint8, device=dev) for _ in range(2)]
 
         def produce(buf):
-            res.run(rows)
-            plan.pack(rows, buf)
+            run.step(rows=rows)
+            _lib.check(L.smc_pack_rows(eng.ctx, rows.data_ptr(), n_mine, buf.data_ptr(), None), "smc_pack_rows")
         pipe = smcdist.RowPipeline(wires, collective=True)
     else:
+        bufs = [rows, torch.empty_like(rows)] if gather else [rows]
+
         def produce(buf):
-            res.run(buf)
-        pipe = smcdist.RowPipeline([rows, plan.alloc_rows()] if gather else [rows], collective=gather)
+            run.step(rows=buf)
+        pipe = smcdist.RowPipeline(bufs, collective=gather)
 
     def step():
         pipe.step(produce)
 
-    for _ in range(a.warmup):
+    for _ in range(max(1, a.warmup)):
         step()
     pipe.drain()
     torch.cuda.synchronize()
+    status = run.status()
+    for k in run.t:
+        run.t[k] = 0
     blocks = []
-    plan.set_timing(min(a.steps * a.blocks, 256))
+    _lib.check(L.smc_build_set_timing(eng.ctx, min(a.steps * a.blocks, 256)), "smc_build_set_timing")
     for _ in range(max(1, a.blocks)):
         torch.cuda.synchronize()
         if use_dist:
@@ -294,19 +338,35 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         blocks.append(elapsed)
-    k_ms, k_n, k_loci, k_reads = plan.kernel_ms()
-    plan.set_timing(0)
+    import ctypes
+    k_ms, k_n = ctypes.c_float(), ctypes.c_int32()
+    _lib.check(L.smc_build_kernel_ms(eng.ctx, ctypes.byref(k_ms), ctypes.byref(k_n)), "smc_build_kernel_ms")
+    L.smc_build_set_timing(eng.ctx, 0)
     elapsed = sorted(blocks)[len(blocks) // 2]                   # the median block
+    # the locus kernels of the same planes, timed alone with one more plan (outside the timed region)
+    plan = run.step(keep_plan=True, rows=rows)
+    torch.cuda.synchronize()
+    plan.set_timing(8)
+    for _ in range(8):
+        plan.run([run.words, run.uaux[0]], params, rows, stream=0)
+    c_ms = plan.kernel_ms()[0]
+    plan.close()
+    torch.cuda.synchronize()
 
     out = None
     if rank == 0:
+        n_steps = max(1, run.t["n"])
         out = {
             "metric": "loci/sec at fixed read-depth x rpb", "value": total_loci * a.steps / elapsed,
             "unit": "loci/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": a.scaling,
             "vs_baseline": None, "dtype": "u8/u32 scan + f64 posterior", "data": "synthetic",
-            "config": {"workload": "%s: %d loci%s x %d reads (%d UMIs x %d rpb), seed %d"
-                       % (cfg.name, n_loc, "/GPU" if a.scaling == "weak" else " in total", cfg.depth, cfg.n_umi, cfg.rpb, cfg.seed),
+            "config": {"workload": "%s: %d loci%s x %d reads (%d UMIs x %d rpb), seed %d; as ALIGNMENTS resident in HBM: %s"
+                       % (cfg.name, n_loc, "/GPU" if a.scaling == "weak" else " in total", cfg.depth, cfg.n_umi, cfg.rpb, cfg.seed,
+                          bench_fa.describe(run, a.config)),
+                       "step": "smc_build_planes (sort, count, the walk that writes one word per pileup read) -> smc_plan_create_dev -> "
+                               "smc_plan_run_words (k_call_v2 + k_filter_loci) -> rows in HBM" + ((" -> %s rows gathered to rank 0"
+                               % ("packed wire" if packed else "full")) if gather else ""),
                        "loci_total": total_loci,
                        "parallelism": "loci sharded x%d, %s" % (world, ("%s rows gathered to rank 0" % ("packed wire" if packed else "full"))
                                                                  if gather else ("single GPU" if world == 1 else
@@ -315,8 +375,13 @@ def main():
                                                                          "check of the N > 1 path, not a measurement"} if share_gpu else {})},
             "blocks": {"n": len(blocks), "steps_each": a.steps, "ms_per_step": [round(b / a.steps * 1e3, 4) for b in blocks],
                        "value_from": "median block", "spread_pct": round(100.0 * (max(blocks) - min(blocks)) / elapsed, 2)},
-            "roofline": roofline_block(res.loci, k_ms, k_n, k_loci, k_reads, "%s:%d" % (a.config, n_mine)),
-            "host_buffers": "inputs resident in HBM when the timed region starts; handing host buffers instead "
+            "roofline": bench_fa.roofline_block(run, k_ms.value, k_n.value, a.config),
+            "step_breakdown": {"k_bp_emit2_ms": k_ms.value, "k_call_v2_ms": c_ms,
+                               "host_ms_per_step": {k: round(v / n_steps * 1e3, 3) for k, v in run.t.items() if k != "n"},
+                               "pileup_reads_per_s": run.reads * a.steps / elapsed, "builder_status": status},
+            "p_value_note": "C3 has no locus that reaches filterVariants (parity.loci_filtered 0): the p-value half of the metric is "
+                            "carried by other_configs X3 / EX / C5",
+            "host_buffers": "inputs resident in HBM when the timed region starts; handing host buffers of planes instead "
                             "(smc_call_batch_host: H2D of 8 B/read + kernels + D2H of the rows) measured 1.94 M loci/s on C3 "
                             "(DESIGN.md section 5) - PCIe-bound, never `value`",
         }
@@ -325,22 +390,26 @@ def main():
             out["cpu_baseline_c_all_cores"] = cpu["c_port_all_cores"]
             out["cpu_baseline_single_process"] = cpu["python_single"]
             out["cpu_baseline_pool_chunked"] = cpu["python_pool_chunked"]
-        if oracle is not None:
-            res.run(rows)
+        if world == 1 and not a.no_parity:
+            run.step(rows=rows)
             torch.cuda.synchronize()
-            out["parity"] = res.parity(rows)
-    res.close()
+            run.rows.free()
+            run.rows = _TensorBuf(rows)
+            out["parity"] = bench_fa.parity_full(run, nthreads, chunk=a.chunk)
+    run.close()
     del rows, pipe
     if rank == 0 and world == 1 and not a.no_other_configs:
+        oracle = None
+        if not a.no_parity:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle_lib as oracle
+        torch.cuda.empty_cache()
+        out["consumer_only"] = other_config(eng, "C3", a, dev, nthreads, oracle)
+        out["consumer_only"]["what"] = ("the locus kernels alone (k_call_v2 bins + k_filter_loci) over read words already resident - the "
+                                        "second half of the step; rounds 1-3 quoted this as `value`")
         out["other_configs"] = {}
         for name in ("C2", "C5", "X3", "EX"):           # X3: 30 % of the loci reach the filters; EX: the example run's statistics
-            if name != a.config:
-                out["other_configs"][name] = other_config(eng, name, a, dev, nthreads, oracle)
-        if not a.no_from_alignments:
-            from smcounter_amd import fa_leg
-            torch.cuda.empty_cache()
-            out["from_alignments"] = fa_leg.run_leg(eng, "C3", a.loci_per_gpu or synth.CONFIGS["C3"].n_loci, max(3, a.steps // 4),
-                                                    2, 3, nthreads, parity_loci=0 if a.no_parity else 512)
+            out["other_configs"][name] = other_config(eng, name, a, dev, nthreads, oracle)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:
@@ -348,9 +417,26 @@ def main():
         dist.destroy_process_group()
 
 
+class _TensorBuf(object):
+    """A torch tensor where bench_fa expects a DevBuf (download / free)."""
+
+    def __init__(self, t):
+        self.t = t
+
+    def download(self, dtype, count, offset_bytes=0):
+        import numpy as np
+        return self.t.cpu().numpy()[offset_bytes:offset_bytes + count * np.dtype(dtype).itemsize].view(dtype).copy()
+
+    def data_ptr(self):
+        return self.t.data_ptr()
+
+    def free(self):
+        self.t = None
+
+
 def other_config(eng, name, a, dev, nthreads, oracle):
-    """The other single-GPU BASELINE configs, same procedure (resident inputs, warm-up, blocks of --steps steps, median
-    block, HIP-event time of the dominant kernel, every row checked), reported as one short object each."""
+    """The locus kernels alone on a single-GPU shape (resident read words, warm-up, blocks of --steps steps, median block,
+    HIP-event time of the dominant kernel, every row checked), reported as one short object."""
     cfg = synth.CONFIGS[name]
     params = synth.params_for(cfg)
     torch.cuda.empty_cache()
@@ -370,12 +456,11 @@ def other_config(eng, name, a, dev, nthreads, oracle):
     k_ms, k_n, k_loci, k_reads = res.plan.kernel_ms()
     res.plan.set_timing(0)
     el = sorted(blocks)[len(blocks) // 2]
-    rf = roofline_block(res.loci, k_ms, k_n, k_loci, k_reads, "%s:%d" % (name, cfg.n_loci))
-    o = {"workload": "%s: %d loci x %d reads (%d UMIs x %d rpb), seed %d" % (name, cfg.n_loci, cfg.depth, cfg.n_umi, cfg.rpb, cfg.seed),
+    o = {"workload": "%s: %d loci x %d reads (%d UMIs x %d rpb), seed %d; read words resident in HBM"
+                     % (name, cfg.n_loci, cfg.depth, cfg.n_umi, cfg.rpb, cfg.seed),
          "value": cfg.n_loci * a.steps / el, "unit": "loci/s", "ms_per_step": el / a.steps * 1e3,
          "blocks_ms_per_step": [round(b / a.steps * 1e3, 4) for b in blocks],
-         "roofline": {k: rf[k] for k in ("achieved", "frac", "frac_basis", "kernel_ms", "loci_per_launch", "needed_bytes_per_launch",
-                                         "achieved_survey_8d", "frac_survey_8d")}}
+         "roofline": call_roofline(res.loci, k_ms, k_n, k_loci, k_reads, "%s:%d" % (name, cfg.n_loci))}
     if oracle is not None:
         res.run(rows)
         torch.cuda.synchronize()
@@ -385,14 +470,17 @@ def other_config(eng, name, a, dev, nthreads, oracle):
 
 
 def cpu_leg(a):
-    """CPU baselines on a bounded sample of the same workload (first chunk of the config):
-    * python_pool - oracle/vc_port.py, the pure-Python restatement of vc(), driven like the reference's
-      main(): multiprocessing.Pool(all host cores), one task per locus, on the first 2000+ loci;
-    * c_port - oracle/smc_oracle.c on one core over the whole first chunk;
-    * c_port_all_cores - the same C code on every host core (threads over contiguous locus ranges)."""
+    """CPU baselines on a bounded sample of the same workload (first chunk of the config), every input made BEFORE its clock
+    starts:
+    * python_pool - oracle/vc_port.py, the pure-Python restatement of vc(), driven like the reference's main():
+      multiprocessing.Pool(all host cores), one task per locus (smCounter.py:683-685) - the loci's pileups generated into
+      each worker before the timed pass (the reference's worker reads its own BAM region: that read is not what is compared);
+    * python_single - the same port in this process, no pool; `ideal_all_cores` = that rate x physical cores;
+    * c_port / c_port_all_cores - oracle/smc_oracle.c on one core / on every host core."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_lib
     import vc_port
+    from smcounter_amd import abi, synth
     cfg = synth.CONFIGS[a.config]
     params = synth.params_for(cfg)
     n_loc = a.loci_per_gpu or cfg.n_loci
@@ -416,10 +504,13 @@ def cpu_leg(a):
     dt_one = time.perf_counter() - t
     n_py = min(n, max(2000, 40 * cores))
     pool = vc_port.make_pool(cores)                 # started and warmed outside the timed region
-    vc_port.call_config(a.config, params, range(cores), pool)          # (first import of the generator in every worker)
+    shared = vc_port.share_batch(sample, n_py)      # the loci's pileups, made before the clock starts, mapped by every worker
+    vc_port.call_shared(shared, params, range(min(n_py, 4 * cores)), pool)   # (every worker has imported and mapped)
     t = time.perf_counter()
-    got = vc_port.call_config(a.config, params, range(n_py), pool)
+    got = vc_port.call_shared(shared, params, range(n_py), pool)
     dt_py = time.perf_counter() - t
+    vc_port.unshare_batch(shared)
+    vc_port.call_config(a.config, params, range(cores), pool)          # (first import of the generator in every worker)
     n_ch = min(n, 40 * cores)
     t = time.perf_counter()
     vc_port.call_config_chunked(a.config, params, 0, n_ch, pool, 20)
@@ -432,13 +523,14 @@ def cpu_leg(a):
     return {
         "python_pool": {"value": n_py / dt_py, "unit": "loci/s", "cores": phys, "logical_cpus": cores, "kind": "port",
                         "per_physical_core": per_core_pool,
+                        "ideal_all_cores": n_one / dt_one * phys,
                         "sample": "first %d loci of the same workload, pure-Python port oracle/vc_port.py under "
-                                  "multiprocessing.Pool(%d), one task per locus as smCounter.py:683-685, every worker making its own "
-                                  "locus's input (the reference's worker reads its own BAM region), %.1f s (pool already started)"
-                                  % (n_py, cores, dt_py)},
+                                  "multiprocessing.Pool(%d), one task per locus as smCounter.py:683-685, %s, %.1f s (pool already "
+                                  "started); ideal_all_cores = the single-process rate x %d physical cores"
+                                  % (n_py, cores, "the loci's pileups made BEFORE the clock starts and mapped by the workers", dt_py, phys)},
         "python_pool_chunked": {"value": n_ch / dt_ch, "unit": "loci/s", "cores": phys, "logical_cpus": cores, "kind": "port",
-                                "sample": "first %d loci, the same pool with 20 consecutive loci per task, %.1f s: without the parent's "
-                                          "per-task round trip (~ 0.4 ms, invisible at the reference's 0.02 - 2 s per locus)" % (n_ch, dt_ch)},
+                                "sample": "first %d loci, the same pool with 20 consecutive loci per task, every worker generating its own "
+                                          "loci inside the clock (rounds 2-3's variant), %.1f s" % (n_ch, dt_ch)},
         "python_single": {"value": n_one / dt_one, "unit": "loci/s", "cores": 1, "kind": "port",
                           "sample": "first %d loci, oracle/vc_port.py in this process (no pool), %.1f s; SURVEY.md section 6 timed the "
                                     "imported reference at ~51 loci/s on one core of the build container for this shape"

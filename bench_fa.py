@@ -1,0 +1,248 @@
+"""bench.py's step: the hot path timed from where the reference's hot loop starts (smCounter.py:316) - a run's ALIGNMENTS
+resident in HBM (what the BAM decoder hands over) -> smc_build_planes (sort, count, scan, the walk that writes the read words:
+csrc/k_build_planes.inc, k_bp_emit2.inc) -> smc_plan_create_dev (launch plan made where the descriptors are) ->
+smc_plan_run_words -> rows in HBM.
+
+A measurement harness beside bench.py (not part of the package): the resident run, its step, and the parity pass - EVERY locus of
+the run against oracle/aln_planes.c (the reference's per-pileup-read logic from the same alignments, on the host cores) +
+oracle/smc_oracle.c.  `python3 -m bench_fa` runs the leg alone (what the rocprofv3 scripts profile).
+"""
+from __future__ import annotations
+
+import ctypes
+import dataclasses
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from smcounter_amd import _lib, abi, synth          # noqa: E402
+from smcounter_amd.engine import DevBuf             # noqa: E402
+from smcounter_amd.features import LOCUS_DTYPE      # noqa: E402
+
+HBM_PEAK_GBS = 8000.0
+
+
+class AlignmentRun(object):
+    """A run of synthetic alignments resident in HBM + the output arrays of smc_build_planes (only what the locus kernels read:
+    the read words).  `shard`: which stretch of the seeded config this rank takes (its loci start n_loci * shard further on,
+    its molecules are drawn from another seed) - the weak-scaling input of rank `shard`."""
+
+    def __init__(self, eng, cfg, params, n_loci, nthreads, shard: int = 0):
+        self.eng, self.params = eng, params
+        if shard:
+            cfg = dataclasses.replace(cfg, seed=cfg.seed + 7919 * shard, start_pos=cfg.start_pos + n_loci * shard)
+        self.cfg = cfg
+        t0 = time.time()
+        kw = {}
+        if os.environ.get("SMC_FA_INDEL_RATE"):                              # (experiments: the share of alignments with an insertion / a deletion)
+            kw = dict(p_ins_aln=float(os.environ["SMC_FA_INDEL_RATE"]), p_del_aln=float(os.environ["SMC_FA_INDEL_RATE"]))
+        A = synth.generate_alignments(cfg, n_loci, params, nthreads=nthreads, **kw)
+        self.t_gen = time.time() - t0
+        self.A = A
+        self.nl, self.ns, self.lo = A["nl"], A["n_slots"], int(A["start0"])
+        self.reads = int(A["reads"])
+        up = lambda a: DevBuf(eng, a.nbytes + 64).upload(a.view(np.uint8).reshape(-1))
+        self.d_in = [up(A[k]) for k in ("aln", "cig", "seq", "qual", "loc")]
+        run_ref = synth.aln_ref_fetch(self.lo, self.lo + self.nl)
+        self.d_ref = up(np.frombuffer(run_ref.encode(), np.uint8).copy())
+        self.words = DevBuf(eng, 4 * (self.ns + 64))
+        self.uaux = [DevBuf(eng, 4 * (self.ns + self.nl + 64)) for _ in range(3)]
+        self.d_loci = DevBuf(eng, self.nl * LOCUS_DTYPE.itemsize)
+        self.xcap = 4 * self.nl + 4096
+        self.d_x = DevBuf(eng, 20 * self.xcap)
+        self.d_cnt = DevBuf(eng, 8)
+        self.loc_host = np.ascontiguousarray(A["loc"])
+        self.bi = abi.SmcBuildIn(self.d_in[0].data_ptr(), self.d_in[1].data_ptr(), self.d_in[2].data_ptr(), self.d_in[3].data_ptr(),
+                                 self.d_in[4].data_ptr(), self.d_ref.data_ptr(), self.lo, self.nl, A["n_bc"], A["n_pair"],
+                                 int(A["loc"]["n"].max()), len(A["aln"]), self.loc_host.ctypes.data)
+        self.cp = abi.c_params(params)
+        self.rows = DevBuf(eng, self.nl * abi.ROW_DTYPE.itemsize)
+        self.lc = np.empty(self.nl, LOCUS_DTYPE)
+        self.host_plan = bool(os.environ.get("SMC_FA_HOST_PLAN"))      # (measurement: descriptors back to the host, smc_plan_create)
+        self.t = {"build_issue": 0.0, "descriptors_d2h": 0.0, "plan_create": 0.0, "run_issue": 0.0, "n": 0}
+
+    def input_bytes(self):
+        A = self.A
+        return int(A["aln"].nbytes + A["cig"].nbytes + A["seq"].nbytes + A["qual"].nbytes + A["loc"].nbytes)
+
+    def needed_bytes(self):
+        """What the walk that writes the read words has to move per launch: per pileup read one base + one quality in and
+        the word out; the alignment records, their row records (written once, read once per tile they touch - counted once)
+        and CIGARs; umi_start and the descriptor per locus."""
+        A = self.A
+        return 2.0 * self.reads + 4.0 * self.ns + (36.0 + 32.0) * len(A["aln"]) + float(A["cig"].nbytes) + 36.0 * self.nl
+
+    def step(self, keep_plan=False, rows=None):
+        """build -> descriptors -> plan -> run; everything the product path does between the decoder and the rows."""
+        eng, L = self.eng, self.eng.L
+        t0 = time.perf_counter()
+        _lib.check(L.smc_build_planes(eng.ctx, ctypes.byref(self.cp), ctypes.byref(self.bi), 0, 0, self.words.data_ptr(), None, None,
+                                      None, None, self.uaux[0].data_ptr(), self.uaux[1].data_ptr(),
+                                      self.uaux[2].data_ptr(), self.d_loci.data_ptr(), self.d_x.data_ptr(), self.xcap,
+                                      self.d_cnt.data_ptr(), ctypes.c_void_p(0)), "smc_build_planes")
+        t1 = time.perf_counter()
+        if self.host_plan:
+            self.d_loci.download(LOCUS_DTYPE, self.nl, out=self.lc)   # (behind the kernels on the default stream)
+            t2 = time.perf_counter()
+            plan = eng.make_plan(self.lc)
+        else:
+            t2 = t1
+            plan = eng.make_plan_dev(self.d_loci, self.nl)            # binned where the descriptors are (waits for the builder)
+        t3 = time.perf_counter()
+        plan.run([self.words, self.uaux[0]], self.params, self.rows if rows is None else rows, stream=0)
+        t4 = time.perf_counter()
+        T = self.t
+        T["build_issue"] += t1 - t0; T["descriptors_d2h"] += t2 - t1; T["plan_create"] += t3 - t2; T["run_issue"] += t4 - t3; T["n"] += 1
+        if keep_plan:
+            return plan
+        plan.close()
+
+    def status(self):
+        return self.d_cnt.download(np.uint32, 2).tolist()
+
+    def close(self):
+        for b in self.d_in + [self.d_ref, self.words, self.d_loci, self.d_x, self.d_cnt, self.rows] + self.uaux:
+            b.free()
+        self.A = None
+
+
+def parity_full(run: AlignmentRun, nthreads: int, n_loci: int = 0, chunk: int = 20000):
+    """Rows of the run's loci (all of them, or `n_loci` spread as a first, a middle and a last stretch) against the CPU: the same
+    alignments through oracle/aln_planes.c (the reference's pileup logic, smCounter.py:316-471) and oracle/smc_oracle.c
+    (:26-98, :482-600), chunk by chunk on the host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_lib
+    got_all = run.rows.download(abi.ROW_DTYPE, run.nl)
+    if n_loci and n_loci < run.nl:
+        third = max(1, n_loci // 3)
+        mid = (run.nl - third) // 2
+        spans = [(0, third), (mid, mid + third), (run.nl - third, run.nl)]
+    else:
+        spans = [(0, run.nl)]
+    tot = {"loci": 0, "mismatches": 0, "fragile_skipped": 0, "near_tie_skipped": 0, "underflow_skipped": 0, "pi_max_abs_diff": 0.0,
+           "loci_filtered": 0, "fisher_tests_run": 0, "p_max_abs_diff": 0.0, "detail": []}
+    t0 = time.time()
+    for a, b in spans:
+        for c0 in range(a, b, chunk):
+            c1 = min(b, c0 + chunk)
+            db = oracle_lib.aln_planes(run.A, run.params, c0, c1, n_threads=nthreads)
+            want, fragile, pi_all = oracle_lib.call_batch_mt(db, abi.c_params(run.params), abi.ROW_DTYPE, nthreads, return_fragile=True,
+                                                             return_pi_all=True)
+            rep = abi.parity_report(got_all[c0:c1], want, fragile, pi_all)
+            for k in ("loci", "mismatches", "fragile_skipped", "near_tie_skipped", "underflow_skipped", "loci_filtered", "fisher_tests_run"):
+                tot[k] += rep[k]
+            for k in ("pi_max_abs_diff", "p_max_abs_diff"):
+                tot[k] = max(tot[k], rep[k])
+            tot["detail"] += [("chunk at locus %d" % c0, d) for d in rep["detail"]]
+    from smcounter_amd import rows as _rows
+    tot["pi_boundary_loci"] = int(len(_rows.pi_boundary_loci(got_all)))
+    tot["detail"] = tot["detail"][:3]
+    tot["spans"] = spans
+    tot["seconds"] = round(time.time() - t0, 1)
+    tot["checked_against"] = ("oracle/aln_planes.c (pileup, allele, barcode / fragment bookkeeping from the same alignments) + "
+                              "oracle/smc_oracle.c, on %d host threads" % nthreads)
+    return tot
+
+
+def traffic_record(key: str):
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        return json.load(open(tpath)).get(key)
+    return None
+
+
+def roofline_block(run: AlignmentRun, k_ms: float, k_n: int, cfg_name: str):
+    need = run.needed_bytes()
+    rec = traffic_record("fa:%s:%d" % (cfg_name, run.nl))
+    traffic = rec["hbm_bytes_per_launch"] / (k_ms * 1e-3) / 1e9 if rec else None
+    return {"bound": "hbm", "kernel": "k_bp_emit2 (the walk that writes the read words: the step's dominant kernel)",
+            "kernel_ms": k_ms, "kernel_samples": k_n, "needed_bytes_per_launch": need,
+            "achieved": need / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": need / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "frac_basis": "needed bytes: 2 B in (base + quality) + 4 B out (the read word) per pileup read, alignment + row records "
+                          "and CIGARs once, umi_start + descriptor per locus; over the kernel's mean HIP-event duration",
+            "reads_per_s_kernel": run.reads / (k_ms * 1e-3),
+            "traffic": traffic, "traffic_measured_in_run": False,
+            "traffic_source": ("profiles/traffic.json <- " + rec.get("source", "rocprofv3 --pmc")) if rec else None,
+            "hbm_bytes_per_launch_pmc": rec["hbm_bytes_per_launch"] if rec else None}
+
+
+def run_leg(eng, cfg_name: str, n_loci: int, steps: int, warmup: int, blocks: int, nthreads: int, parity_loci: int = -1):
+    """The leg on one GPU, alone (scripts, `python3 -m bench_fa`); bench.py drives the same pieces itself."""
+    cfg = synth.CONFIGS[cfg_name]
+    params = synth.params_for(cfg)
+    L = eng.L
+    run = AlignmentRun(eng, cfg, params, n_loci, nthreads)
+    for _ in range(max(1, warmup)):
+        run.step()
+    L.smc_device_sync(eng.ctx)
+    st = run.status()
+    for k in run.t:
+        run.t[k] = 0
+    _lib.check(L.smc_build_set_timing(eng.ctx, min(256, steps * blocks)), "smc_build_set_timing")
+    times = []
+    for _ in range(max(1, blocks)):
+        L.smc_device_sync(eng.ctx)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run.step()
+        L.smc_device_sync(eng.ctx)
+        times.append(time.perf_counter() - t0)
+    k_ms, k_n = ctypes.c_float(), ctypes.c_int32()
+    _lib.check(L.smc_build_kernel_ms(eng.ctx, ctypes.byref(k_ms), ctypes.byref(k_n)), "smc_build_kernel_ms")
+    L.smc_build_set_timing(eng.ctx, 0)
+    # the locus kernels of the same planes, timed alone with the last plan
+    plan = run.step(keep_plan=True)
+    L.smc_device_sync(eng.ctx)
+    plan.set_timing(8)
+    for _ in range(8):
+        plan.run([run.words, run.uaux[0]], params, run.rows, stream=0)
+    c_ms = plan.kernel_ms()[0]
+    plan.close()
+    el = sorted(times)[len(times) // 2]
+    n = max(1, run.t["n"])
+    out = {
+        "workload": describe(run, cfg_name),
+        "step": "smc_build_planes (read words) -> smc_plan_create_dev (binning on the device) -> smc_plan_run_words -> rows in HBM",
+        "value": run.nl * steps / el, "unit": "loci/s", "ms_per_step": el / steps * 1e3,
+        "blocks_ms_per_step": [round(t / steps * 1e3, 3) for t in times],
+        "pileup_reads_per_s": run.reads * steps / el,
+        "host_ms_per_step": {k: round(v / n * 1e3, 3) for k, v in run.t.items() if k != "n"},
+        "k_call_v2_ms": c_ms,
+        "roofline": roofline_block(run, k_ms.value, k_n.value, cfg_name),
+        "builder_status": st,
+        "generate_s": round(run.t_gen, 1),
+    }
+    if parity_loci:
+        run.step()
+        L.smc_device_sync(eng.ctx)
+        out["parity"] = parity_full(run, nthreads, 0 if parity_loci < 0 else parity_loci)
+    run.close()
+    return out
+
+
+def describe(run: AlignmentRun, cfg_name: str) -> str:
+    return ("%s-shaped alignments: %d loci, %d alignments (%d barcodes, %d fragments), %d pileup reads, depth %.0f; resident in HBM "
+            "(%.2f GB)" % (cfg_name, run.nl, len(run.A["aln"]), run.A["n_bc"], run.A["n_pair"], run.reads, run.reads / run.nl,
+                           run.input_bytes() / 1e9))
+
+
+if __name__ == "__main__":
+    import argparse
+    from smcounter_amd.engine import Engine
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="C3")
+    ap.add_argument("--loci", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--blocks", type=int, default=3)
+    ap.add_argument("--parity-loci", type=int, default=-1, help="-1: every locus; 0: none; n: n loci as a first, a middle and a last stretch")
+    a = ap.parse_args()
+    eng = Engine(0)
+    cfg = synth.CONFIGS[a.config]
+    print(json.dumps(run_leg(eng, a.config, a.loci or cfg.n_loci, a.steps, a.warmup, a.blocks, len(os.sched_getaffinity(0)), a.parity_loci)))

@@ -256,6 +256,57 @@ def call_config(cfg_name, params, loci, pool):
     return [r.get() for r in results]
 
 
+_SHARED = {}
+
+
+def share_batch(db, n_loci, directory=None):
+    """The first `n_loci` loci of a batch written where every worker can map them (made BEFORE a timed pass: the workers then
+    read their locus's reads from it as the reference's worker reads its BAM region - the making of the input is not what a CPU
+    baseline should time).  -> the directory."""
+    import os
+    import tempfile
+    d = tempfile.mkdtemp(prefix="smc_cpu_leg_", dir=directory or ("/dev/shm" if os.path.isdir("/dev/shm") else None))
+    end = 4 * int(db.loci["read_off4"][n_loci - 1]) + int(db.loci["n_reads"][n_loci - 1])
+    for name in ("meta", "umi", "frag", "dist"):
+        np.save(os.path.join(d, name + ".npy"), getattr(db, name)[:end])
+    np.save(os.path.join(d, "loci.npy"), db.loci[:n_loci])
+    return d
+
+
+def unshare_batch(d):
+    import shutil
+    shutil.rmtree(d, ignore_errors=True)
+
+
+def _task_shared(args):
+    """One locus whose reads the worker takes from the shared batch (mapped once per worker)."""
+    d, l, prm = args
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from smcounter_amd.params import VcParams
+    B = _SHARED.get(d)
+    if B is None:
+        B = _SHARED[d] = {k: np.load(os.path.join(d, k + ".npy"), mmap_mode="r") for k in ("meta", "umi", "frag", "dist", "loci")}
+    P = VcParams(**prm)
+    L = B["loci"][l]
+    o, n = 4 * int(L["read_off4"]), int(L["n_reads"])
+    return vc_locus(np.asarray(B["meta"][o:o + n]), np.asarray(B["umi"][o:o + n]), np.asarray(B["frag"][o:o + n]) & 0x07FFFFFF,
+                    np.asarray(B["dist"][o:o + n]), int(L["ref_allele"]), int(L["n_alleles"]), int(L["snp_mask"]), P.minBQ, P.minMQ,
+                    P.mtDrop, P.primerDist, P.ds, P.smt, None)
+
+
+def call_shared(d, params, loci, pool):
+    """The port over loci of a shared batch, one task per locus (smCounter.py:683-685): the parent sends a directory name and a
+    locus index."""
+    prm = dict(minBQ=params.minBQ, minMQ=params.minMQ, mtDepth=params.mtDepth, rpb=params.rpb, hpLen=params.hpLen,
+               mismatchThr=params.mismatchThr, mtDrop=params.mtDrop, maxMT=params.maxMT, primerDist=params.primerDist)
+    results = [pool.apply_async(_task_shared, ((d, int(l), prm),)) for l in loci]
+    return [r.get() for r in results]
+
+
 def _noop(x):
     return x
 

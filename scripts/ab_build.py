@@ -6,7 +6,8 @@ import ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
-from smcounter_amd import _lib, abi, synth, engine, fa_leg
+from smcounter_amd import _lib, abi, synth, engine
+import bench_fa as fa_leg
 
 n = int(sys.argv[1]); libs = sys.argv[2:]
 cfgname = os.environ.get("AB_CFG", "C3")

@@ -5,7 +5,8 @@ import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
-from smcounter_amd import _lib, abi, synth, engine, fa_leg
+from smcounter_amd import _lib, abi, synth, engine
+import bench_fa as fa_leg
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
 copies = int(sys.argv[2]) if len(sys.argv) > 2 else 3

@@ -28,7 +28,7 @@ timeout 300 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_HIT_sum 
 echo "== C3 request sizes" >> $O/pmc_summary.txt
 python3 $R/scripts/pmc_summary.py $O/rdreq_C3 $O/wrreq_C3 >> $O/pmc_summary.txt
 # the from_alignments leg: traffic and SQ counters of the plane builder's kernels
-FA="-m smcounter_amd.fa_leg --config C3 --steps 2 --warmup 1 --blocks 1 --parity-loci 0"
+FA="-m bench_fa --config C3 --steps 2 --warmup 1 --blocks 1 --parity-loci 0"
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" \
   "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
   "SQ_BUSY_CYCLES SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do

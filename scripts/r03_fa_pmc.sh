@@ -2,7 +2,7 @@
 # PMC passes over the from_alignments leg (smcounter_amd.fa_leg) at a given size.  usage: bash scripts/r03_fa_pmc.sh TAG LOCI [quick]
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-fa_pmc}; N=${2:-200000}; Q=${3:-}; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp; export PYTHONPATH=$R
-ARGS="-m smcounter_amd.fa_leg --config C3 --loci $N --steps 2 --warmup 1 --blocks 1 --parity-loci 0"
+ARGS="-m bench_fa --config C3 --loci $N --steps 2 --warmup 1 --blocks 1 --parity-loci 0"
 run() { timeout 240 rocprofv3 --pmc $2 --output-format csv -d $O/$1 -- python3 $ARGS > /dev/null 2>&1 || echo "pass $1 failed/timeout"; }
 run sq "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
 run sq2 "SQ_BUSY_CYCLES SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS"

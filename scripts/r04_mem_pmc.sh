@@ -2,7 +2,7 @@
 # memory-side PMC passes over the from_alignments leg (bench_fa).  usage: bash scripts/r04_mem_pmc.sh TAG LOCI
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-mem_pmc}; N=${2:-200000}; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp; export PYTHONPATH=$R
-ARGS="-m smcounter_amd.fa_leg --config C3 --loci $N --steps 2 --warmup 1 --blocks 1 --parity-loci 0"
+ARGS="-m bench_fa --config C3 --loci $N --steps 2 --warmup 1 --blocks 1 --parity-loci 0"
 run() { timeout 240 rocprofv3 --pmc $2 --output-format csv -d $O/$1 -- python3 $ARGS > /dev/null 2>&1 || echo "pass $1 failed/timeout"; }
 run m1 "TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TOTAL_WAVEFRONTS_sum"
 run m2 "TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum"

@@ -3,7 +3,7 @@
 # usage: bash scripts/r04_pmc.sh TAG LIBNAME LOCI "COUNTERS OF PASS 1" "COUNTERS OF PASS 2" ...
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$1; LIB=$2; N=$3; shift 3; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp; export PYTHONPATH=$R; export SMC_HIP_LIB=$R/smcounter_amd/$LIB
-ARGS="-m smcounter_amd.fa_leg --config C3 --loci $N --steps 2 --warmup 1 --blocks 1 --parity-loci 0"
+ARGS="-m bench_fa --config C3 --loci $N --steps 2 --warmup 1 --blocks 1 --parity-loci 0"
 i=0; dirs=""
 for P in "$@"; do
   i=$((i+1))

@@ -213,6 +213,50 @@ def test_four_ranks_uneven_shares_and_empty_ranks_write_the_single_process_files
     assert any("INS|" in r or "DEL|" in r or len(r.split("\t")[2]) > 1 or len(r.split("\t")[3]) > 1 for r in got)
 
 
+def _eight_way_weights(n):
+    """Eight ranks (integer weights, total 80, a cut every 10): locus 0 alone on rank 0, nothing for ranks 1-3, two loci for
+    rank 4, one each for ranks 5 and 6, the rest for rank 7."""
+    w = [0] * n
+    w[0] = 40
+    w[1] = w[2] = 5
+    w[3] = w[4] = w[5] = 10
+    return w
+
+
+@pytest.mark.timeout(420)
+def test_eight_ranks_with_empty_single_and_large_shares_write_the_single_process_files(tmp_path):
+    """The launch shape of the driver's 8-GPU run (one process per rank, one gather to rank 0) with shares of 0, 1, 2 and many
+    loci: the same all.txt as one process writes."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bam_fixture
+    from smcounter_amd import dist
+    case = bam_fixture.make_case(str(tmp_path))
+    for k, name in (("bam", "case.bam"), ("bed", "case.bed"), ("fasta", "case.fa")):
+        os.replace(case[k], str(tmp_path / name))
+    if os.path.exists(case["fasta"] + ".fai"):
+        os.replace(case["fasta"] + ".fai", str(tmp_path / "case.fa.fai"))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cli_worker, args=(r, 8, port, str(tmp_path), q, _eight_way_weights)) for r in range(8)]
+    for p in procs:
+        p.start()
+    assert q.get(timeout=360) == 10
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want, loci = _single_process_expectation(tmp_path)
+    cuts = dist.shard_by_reads(_eight_way_weights(len(loci)), 8)
+    shares = [cuts[r + 1] - cuts[r] for r in range(8)]
+    assert shares[:7] == [1, 0, 0, 0, 2, 1, 1] and shares[7] == len(loci) - 5 > 2, shares
+    got = open(str(tmp_path / "dist.smCounter.all.txt")).read().split("\n")[1:-1]
+    assert got == want and len(got) == len(loci)
+
+
 @pytest.mark.timeout(300)
 def test_two_rank_command_line_writes_the_single_process_files(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
