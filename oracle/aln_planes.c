@@ -79,7 +79,7 @@ typedef struct { uint32_t meta, umi, fidx, cls, dist, order; } read_t;
 
 /* planes of loci [l0, l1) of the run.  loc[l].slot_off / .n as the decoder counted them; locus l's reads go to plane slots
  * slot_base + slot_off .., its umi_start entries to umi_base + slot_off + l ..  Returns 0, or -1 out of memory, -2 a locus whose
- * depth differs from loc[l].n, -3 an alignment flagged neither READ1 nor READ2, -4 more than 64 alleles, -5 a quality > 126 */
+ * depth differs from loc[l].n, -3 a pileup that begins with an alignment flagged neither READ1 nor READ2, -4 more than 64 alleles, -5 a quality > 126 */
 int smc_aln_planes(const smc_dev_aln* aln, const uint32_t* cig, const uint8_t* seq, const uint8_t* qual, const smc_dev_locus* loc,
                    const uint8_t* refseq, int32_t start0, int32_t l0, int32_t l1, int32_t min_bq, int32_t min_mq, int32_t primer_dist,
                    uint32_t fp, uint32_t slot_base, uint32_t umi_base, uint32_t* meta, uint32_t* umi, uint32_t* frag, uint32_t* dist,
@@ -100,13 +100,16 @@ int smc_aln_planes(const smc_dev_aln* aln, const uint32_t* cig, const uint8_t* s
         const uint32_t so = slot_base + loc[l].slot_off, uo = umi_base + loc[l].slot_off + (uint32_t)l;
         memset(tb, 0, sizeof(slot_t) * tsz); memset(tf, 0, sizeof(slot_t) * tsz);
         uint32_t n = 0, n_umi = 0, n_frag = 0, n_extra = 0;
+        int pair_r2 = -1;
         uint64_t xhash[58];
         uint32_t xsingle[58], xletter[58];
         for (uint32_t a = loc[l].w0; a < loc[l].w1 && rc == 0; ++a) {
             const smc_dev_aln* A = aln + a;
             if (!(A->pos <= p && p < A->end)) continue;
             if (n >= loc[l].n) { rc = -2; break; }
-            if (!(A->oflag & (SMC_DA_R1 | SMC_DA_R2))) { rc = -3; break; }
+            /* pairOrder (smCounter.py:359-362): R2 wins over R1; neither - the value the previous pileup read left behind */
+            if (A->oflag & (SMC_DA_R1 | SMC_DA_R2)) pair_r2 = (A->oflag & SMC_DA_R2) != 0;
+            else if (pair_r2 < 0) { rc = -3; break; }
             const res_t r = resolve(cig + A->cig_off, A->n_cig, A->pos, p, A->l_seq);
             const int gap = (r.isdel && r.indel == 0) || r.qpos < 0;
             const int kind = r.indel > 0 ? 2 : r.indel < 0 ? 3 : r.isdel ? 1 : 0;
@@ -127,7 +130,7 @@ int smc_aln_planes(const smc_dev_aln* aln, const uint32_t* cig, const uint8_t* s
                 }
                 al = 6u + k;
             }
-            const int r2 = (A->oflag & SMC_DA_R2) != 0, rev = (A->oflag & SMC_DA_REV) != 0, mmok = (A->oflag & SMC_DA_MMOK) != 0;
+            const int r2 = pair_r2, rev = (A->oflag & SMC_DA_REV) != 0, mmok = (A->oflag & SMC_DA_MMOK) != 0;
             uint32_t dbc = 0, dpr = 0;
             if (kind == 0) {                                                  /* :432-452 */
                 const int rel = r.qpos - (int)A->left_sp, far = (int)A->qalen - rel;

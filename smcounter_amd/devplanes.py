@@ -202,7 +202,10 @@ def build_run(A, L, eng, cp, params, chrom, lo, fasta, run_ref, planes, uaux, sl
     if nl == 0:
         return 0, 0, np.zeros(0, LOCUS_DTYPE), []
     deepest = int(A["loc"]["n"].max()) if len(A["loc"]) else 0
-    if A["status"] != 0 or deepest > max_depth or slot_base + ns > cap or \
+    # (status bit 1 - an alignment flagged neither READ1 nor READ2 - no longer sends the run to the host builder: the walk's
+    # exact path takes the previous pileup read's pairOrder, smCounter.py:359-362)
+    ok_status = 0 if os.environ.get("SMC_BP_EMIT") == "old" else 1       # (round 3's walk, kept for A/B runs, has no such path)
+    if (A["status"] & ~ok_status) != 0 or deepest > max_depth or slot_base + ns > cap or \
             umi_base + ns + nl + 1 > cap + 8192:
         return None
     up = lambda a: DevBuf(eng, a.nbytes + 64).upload(a.view(np.uint8).reshape(-1) if a.nbytes else np.zeros(4, np.uint8))

@@ -11,8 +11,12 @@ smc_bam_planes) and the locus kernels.
 
 Cases:  cigars  - two chromosomes, random S/M/I/D/N CIGARs incl. D next to I, hard clips, reads without NM, odd read names;
         deep    - a core of > 8192 reads per locus with shallow flanks, giant and tiny barcodes, indels, soft clips;
-        overcap - more barcodes than 2 * mtDepth: the reference's random.sample on barcode texts (py2 emulation).
-Usage:  PYTHONHASHSEED=0 python tests/golden/make_bam_golden.py
+        overcap - more barcodes than 2 * mtDepth: the reference's random.sample on barcode texts (py2 emulation);
+        deep25k - a core beyond 24,576 reads per locus (the locus kernels' deep class: parts and chunks; the plane builder's
+                  multi-launch sort) between shallow flanks, one giant barcode, indels;
+        unflagged - alignments flagged neither READ1 nor READ2 among paired ones: the reference's pairOrder is then the value the
+                  PREVIOUS pileup read left behind (smCounter.py:359-362).
+Usage:  PYTHONHASHSEED=0 python tests/golden/make_bam_golden.py [case ...]
 """
 import dataclasses
 import json
@@ -246,7 +250,74 @@ def case_overcap():
     emit("bam_overcap", [("chrO", L)], {"chrO": ref}, recs, loci, VcParams(mtDepth=9, rpb=2.5, hpLen=8))      # ds = 18 < ~60 barcodes
 
 
+def case_deep25k():
+    rng = np.random.RandomState(20174)
+    L = 500
+    ref = "".join(rng.choice(list("ACGT"), L))
+    recs = []
+    n_bc = 2600
+    for i in range(13400):
+        bc = int(rng.randint(0, n_bc)) if i % 5 else 0                                # one giant barcode (a fifth of the reads)
+        deep = i % 60 != 0
+        start = 250 + int(rng.randint(0, 4)) if deep else int(rng.randint(150, 330))
+        variant = bc % 9 == 1
+        for mate in (0, 1):
+            pos = start + (0 if mate == 0 else int(rng.randint(0, 5)))
+            k = rng.rand()
+            if k < 0.01:
+                cig = [(0, 20), (1, 1), (0, 29)]
+            elif k < 0.02:
+                cig = [(0, 24), (2, 2), (0, 26)]
+            elif k < 0.04:
+                cig = [(4, 3), (0, 47)]
+            else:
+                cig = [(0, 50)]
+            s = read_from_ref(rng, ref, pos, cig, p_err=0.003)
+            if variant:
+                a = bamio.Alignment(); a.pos, a.cigar, a.l_seq = pos, cig, len(s)
+                col = bamio._column(a, 270)
+                if col is not None and not col[1]:
+                    s = s[:col[0]] + {"A": "C", "C": "A", "G": "T", "T": "G"}[ref[270]] + s[col[0] + 1:]
+            recs.append(dict(tid=0, pos=pos, qname="r%d:NN:BC%04d:y" % (i, bc), flag=(0x41 if mate == 0 else 0x91), mapq=int(rng.choice([25, 60, 60])),
+                             cigar=cig, seq=s, qual=[int(x) for x in rng.choice([12, 25, 30, 37], len(s))], nm=int(rng.randint(0, 2))))
+    loci = [("chrE", str(p)) for p in (249, 252, 262, 271, 280, 296, 306)]
+    emit("bam_deep25k", [("chrE", L)], {"chrE": ref}, recs, loci, VcParams(mtDepth=3000, rpb=8.0, hpLen=8, mtDrop=1))
+
+
+def case_unflagged():
+    rng = np.random.RandomState(20175)
+    L = 400
+    ref = "".join(rng.choice(list("ACGT"), L))
+    recs = []
+    for u in range(40):
+        umi = "".join(rng.choice(list("ACGT"), 10))
+        for fr in range(rng.randint(1, 5)):
+            start = 150 + int(rng.randint(0, 25))
+            for mate in (0, 1):
+                if mate == 1 and rng.rand() < 0.3:
+                    continue
+                pos = start + (0 if mate == 0 else int(rng.randint(0, 8)))
+                cig = [(0, 60)] if rng.rand() < 0.85 else [(4, 2), (0, 28), (2, 2), (0, 30)]
+                s = read_from_ref(rng, ref, pos, cig, p_err=0.01)
+                flag = (0x40 if mate == 0 else 0x80) | (0x10 if rng.rand() < 0.5 else 0) | 1
+                if rng.rand() < 0.12:
+                    flag &= ~0xC0                                             # neither READ1 nor READ2
+                recs.append(dict(tid=0, pos=pos, qname="q%d_%d:NN:%s:z" % (u, fr, umi), flag=flag, mapq=60, cigar=cig,
+                                 seq=s, qual=[int(x) for x in rng.choice([10, 25, 30, 37], len(s))], nm=int(rng.randint(0, 2))))
+    # the first record of the file keeps its flags: a pileup that STARTS with an unflagged read has no pairOrder in the reference
+    recs.sort(key=lambda r: r["pos"])
+    loci = [("chrU", str(p)) for p in range(160, 225)]
+    for _, p in loci:
+        p0 = int(p) - 1
+        for r in recs:                                                        # (file order = pileup order)
+            if r["pos"] <= p0 < r["pos"] + sum(l for op, l in r["cigar"] if op in (0, 2, 3, 7, 8)):
+                if not (r["flag"] & 0xC0):
+                    r["flag"] |= 0x40
+                break
+    emit("bam_unflagged", [("chrU", L)], {"chrU": ref}, recs, loci, VcParams(mtDepth=100, rpb=3.0, hpLen=8, primerDist=3))
+
+
 if __name__ == "__main__":
-    case_cigars()
-    case_deep()
-    case_overcap()
+    todo = sys.argv[1:] or ["cigars", "deep", "overcap", "deep25k", "unflagged"]
+    for name in todo:
+        globals()["case_" + name]()

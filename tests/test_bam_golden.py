@@ -19,7 +19,7 @@ from smcounter_amd import abi, bamio, fasta, features, pileup, rows
 from smcounter_amd.params import VcParams
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-CASES = ("bam_cigars", "bam_deep", "bam_overcap")
+CASES = ("bam_cigars", "bam_deep", "bam_overcap", "bam_deep25k", "bam_unflagged")
 
 
 def load_case(name, tmp_path):

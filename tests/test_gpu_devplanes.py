@@ -74,27 +74,67 @@ def test_device_planes_on_the_variant_fixture_and_rows(engine0, tmp_path):
     assert any(len(t) > 6 for _, hb in host for t in hb.alleles)      # indel alleles went through the extras list
 
 
-def test_runs_the_device_path_does_not_take_fall_back(engine0, tmp_path):
-    """An alignment with neither READ1 nor READ2 (the reference's pairOrder is then carried over between pileup reads,
-    smCounter.py:359-362) sends its run to the host builder; the batch is the same."""
+def test_alignments_flagged_neither_read1_nor_read2(engine0, tmp_path):
+    """An alignment with neither READ1 nor READ2: the reference's pairOrder is then whatever the previous pileup read left
+    (smCounter.py:359-362).  The device builder takes such a run itself (the walk's exact path looks the previous covering
+    alignment up); the batch equals the host builder's.  A pileup that BEGINS with such an alignment - the reference fails
+    there - goes back to the host builder, which raises."""
     from smcounter_amd import devplanes
+    from smcounter_amd.features import PileupError
     ref = "ACGTTGCAAC" * 30
     fa_path = str(tmp_path / "d.fa")
     open(fa_path, "w").write(">chrD\n" + ref + "\n")
-    recs = [dict(tid=0, pos=10 + (i % 7), qname="r%d:x:BC%d:y" % (i // 2, i % 5), flag=(0x41 if i % 2 == 0 else 0x91) if i != 9 else 0x10,
-                 mapq=60, cigar=[(0, 40)], seq=ref[10 + (i % 7):50 + (i % 7)], qual=[30] * 40, nm=0) for i in range(40)]
-    recs.sort(key=lambda r: r["pos"])
-    bam = str(tmp_path / "d.bam")
-    bamio.write_bam(bam, [("chrD", len(ref))], recs)
-    bamio.write_bai(bam)
+
+    def make(unflagged):
+        recs = [dict(tid=0, pos=10 + (i % 7), qname="r%d:x:BC%d:y" % (i // 2, i % 5), flag=(0x41 if i % 2 == 0 else 0x91) if i not in unflagged else 0x10,
+                     mapq=60, cigar=[(0, 40)], seq=ref[10 + (i % 7):50 + (i % 7)], qual=[30] * 40, nm=0) for i in range(40)]
+        recs.sort(key=lambda r: r["pos"])
+        bam = str(tmp_path / ("d%d.bam" % len(unflagged)))
+        bamio.write_bam(bam, [("chrD", len(ref))], recs)
+        bamio.write_bai(bam)
+        return bam
     fa = fasta.FastaFile(fa_path)
     loci = [("chrD", str(p)) for p in range(15, 45)]
     P = VcParams(mtDepth=100, rpb=2.0)
+    bam = make({9, 16, 17, 30})
     host = list(bamio.iter_device_batches_native(bam, fa, loci, P))
     dev = list(devplanes.iter_resident_batches(bam, fa, loci, P, engine0))
     for (_, hb), (_, rb) in zip(host, dev):
         _same_batch(rb, hb)
-        assert rb.n_device_runs == 0 and rb.n_host_runs >= 1
+        assert rb.n_device_runs >= 1 and rb.n_host_runs == 0
+    # the first record of the file unflagged: no pairOrder to carry over
+    bam = make({0})
+    with pytest.raises(PileupError):
+        list(devplanes.iter_resident_batches(bam, fa, loci, P, engine0))
+
+
+def test_a_locus_with_more_than_64_alleles_is_refused(engine0, tmp_path):
+    """70 different insertions behind one position: beyond the 64 allele ids a locus's table holds (SMC_MAX_ALLELES).  The device
+    builder flags the run (status 8), the host builder it falls back to says which locus - no batch is made of it."""
+    from smcounter_amd import devplanes
+    rng = np.random.default_rng(64)
+    ref = "".join(rng.choice(list("ACGT"), size=300))
+    fa_path = str(tmp_path / "a.fa")
+    open(fa_path, "w").write(">chrA\n" + ref + "\n")
+    recs = []
+    seen = set()
+    while len(seen) < 70:
+        ins = "".join(rng.choice(list("ACGT"), size=int(rng.integers(1, 5))))
+        if ins in seen:
+            continue
+        seen.add(ins)
+        i = len(seen)
+        recs.append(dict(tid=0, pos=100, qname="r%d:x:BC%02d:y" % (i, i % 9), flag=0x41, mapq=60, cigar=[(0, 30), (1, len(ins)), (0, 20)],
+                         seq=ref[100:130] + ins + ref[130:150], qual=[30] * (50 + len(ins)), nm=len(ins)))
+    bam = str(tmp_path / "a.bam")
+    bamio.write_bam(bam, [("chrA", len(ref))], recs)
+    bamio.write_bai(bam)
+    fa = fasta.FastaFile(fa_path)
+    loci = [("chrA", str(p)) for p in range(120, 140)]
+    P = VcParams(mtDepth=100, rpb=2.0)
+    with pytest.raises(Exception) as e:
+        list(devplanes.iter_resident_batches(bam, fa, loci, P, engine0))
+    assert "64" in str(e.value) and "alleles" in str(e.value)
 
 
 @pytest.mark.parametrize("depth", [9000, 40000])
