@@ -80,3 +80,29 @@ def test_lod_root_and_edge_cases(tmp_path):
     assert lines[1].endswith("\t1") and lines[2].endswith("\t1") and 0 < float(lines[0].split("\t")[3]) < 0.05
     q = (tmp_path / "lod.bedgraph.quantiles.txt").read_text().splitlines()
     assert [x.split("|")[0] for x in q] == ["1%", "5%", "10%", "50%", "90%", "95%", "99%"]
+
+
+def test_down_samplers_against_what_the_reference_scripts_wrote():
+    """tests/golden/tools_ds.npz (make_tools_golden.py, build container): the read names ds.mt.py and ds.reads.withinMT.py
+    themselves wrote - run through lib2to3 with a stub pysam and a py2-ordered dict - for three inputs (5, 40 and 300 barcodes:
+    below and beyond the resizes of a py2 dict) and three (seed, parameter) pairs each.  The tools' selection rules
+    (tools/ds_mt.select_barcodes, tools/ds_reads_within_mt.select_reads: py2 key order + Py2Random) must pick the same
+    records, in the same order."""
+    import json
+    import os
+    from conftest import ROOT
+    z = np.load(os.path.join(ROOT, "tests", "golden", "tools_ds.npz"))
+    cases = json.loads(bytes(z["meta"]).decode())
+    n_runs = 0
+    for case in cases:
+        q = case["qnames"]
+        for run in case["runs"]:
+            if run["script"] == "ds.mt.py":
+                kept = ds_mt.select_barcodes(q, run["pct"], run["seed"])
+                got = [x for x in q if ds_mt.barcode_of(x) in kept]
+            else:
+                sel, _ = ds_reads_within_mt.select_reads(q, run["rpb"], run["seed"])
+                got = [x for x in q if x in sel]
+            assert got == run["written"], (run["script"], run["seed"], len(got), len(run["written"]))
+            n_runs += 1
+    assert n_runs == 18
