@@ -382,6 +382,10 @@ int smc_build_planes(smc_ctx* ctx, const smc_params* params, const smc_build_in*
                      uint32_t* words, uint32_t* meta, uint32_t* umi, uint32_t* frag, uint32_t* dist, uint32_t* umi_start,
                      uint32_t* u_gid, uint32_t* u_finc, smc_locus* loci, uint32_t* xlist, uint32_t xcap, uint32_t* counters, void* stream);
 
+/* The context keeps the device blocks of destroyed plans for the next plan (at most 64 blocks / 8 GB; the oldest goes first).
+ * smc_pool_trim waits for the plans' last runs and returns every pooled block to the runtime. */
+int smc_pool_trim(smc_ctx* ctx);
+
 /* Device memory for callers without a GPU runtime of their own (the Python command line uses these instead of importing
  * PyTorch: about a second of start-up): allocation, synchronous copies, device synchronisation. */
 int smc_mem_alloc(smc_ctx* ctx, int64_t bytes, void** out);

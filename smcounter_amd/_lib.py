@@ -15,7 +15,7 @@ SYMBOLS = ("smc_abi_version", "smc_last_error", "smc_row_size", "smc_locus_size"
            "smc_plan_run", "smc_plan_run_words", "smc_pack_words", "smc_plan_set_timing", "smc_plan_kernel_ms", "smc_call_batch_host", "smc_event_create", "smc_event_record",
            "smc_event_elapsed_ms", "smc_event_destroy", "smc_class_table", "smc_wire_row_size", "smc_pack_rows", "smc_unpack_rows",
            "smc_build_planes", "smc_build_max_depth", "smc_build_set_timing", "smc_build_kernel_ms", "smc_mem_alloc", "smc_mem_free", "smc_mem_h2d", "smc_mem_d2h",
-           "smc_mem_alloc_host", "smc_mem_free_host",
+           "smc_mem_alloc_host", "smc_mem_free_host", "smc_pool_trim",
            "smc_device_sync")
 
 
@@ -82,6 +82,7 @@ def load(with_torch: bool = True):
     L.smc_mem_h2d.argtypes = [vp, vp, vp, i64]
     L.smc_mem_d2h.argtypes = [vp, vp, vp, i64]
     L.smc_device_sync.argtypes = [vp]
+    L.smc_pool_trim.argtypes = [vp]
     L.smc_build_max_depth.restype = ctypes.c_int
     L.smc_build_set_timing.argtypes = [vp, ctypes.c_int]
     L.smc_build_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32)]

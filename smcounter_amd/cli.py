@@ -166,12 +166,12 @@ def _report_boundary(out_rows, chrom, pos):
     from . import rows as _rows
     idx = _rows.pi_boundary_loci(out_rows)
     for l in idx.tolist():
-        print("note: prediction index of %s:%d lies within 1e-8 of a printing boundary" % (chrom[l], int(pos[l])))
+        print("note: prediction index of %s:%d lies within 1e-8 of a printing boundary" % (chrom[l], int(pos[l])), file=sys.stderr)
     import numpy as np
     from . import abi
     for l in np.flatnonzero((out_rows["status"] & abi.ST_UNDERFLOW) != 0).tolist():
         print("note: a barcode at %s:%d has so many fragments that the posterior arithmetic left the double range; the "
-              "reference's own numbers there depend on its multiplication order" % (chrom[l], int(pos[l])))
+              "reference's own numbers there depend on its multiplication order" % (chrom[l], int(pos[l])), file=sys.stderr)
 
 
 class _Rows(list):
@@ -320,7 +320,7 @@ def _main(args) -> int:
     print("begin variant filtering and output")
     have_rep = [b for b in (args.bedTandemRepeats, args.bedRepeatMaskerSubset) if b and os.path.exists(b)]
     if len(have_rep) < 2:
-        print("note: repeat tracks not given or not found; RepT/RepS/LowC/SL flags are not applied")
+        print("note: repeat tracks not given or not found; RepT/RepS/LowC/SL flags are not applied", file=sys.stderr)
     trf, rm = postfilter.load_repeat_regions(
         args.bedTarget,
         args.bedTandemRepeats if args.bedTandemRepeats and os.path.exists(args.bedTandemRepeats) else None,

@@ -74,6 +74,18 @@ def pack_words_host(meta: np.ndarray, frag: np.ndarray, loci: np.ndarray) -> np.
     np.add.at(d, start + n, -1)
     valid = np.cumsum(d[:-1]) > 0
     cls = frag >> np.uint32(FRAG_CLASS_SHIFT)
+    # the slot contract, checked as k_pack_words.inc checks it: within a locus the slots start at 0, step by 0 or 1 and end at
+    # n_frag - 1; a read that breaks it gets class 31 (no read class), which the kernels answer with SMC_ST_BAD_INPUT
+    prev = np.empty(ns, np.uint32)
+    prev[1:] = slot[:-1]
+    prev[:1] = 0
+    prev[start[n > 0]] = np.uint32(0xFFFFFFFF)
+    step = slot - prev
+    bad = step > np.uint32(1)
+    last = (start + n - 1)[n > 0]
+    bad[last] |= slot[last] != (loci["n_frag"][n > 0].astype(np.int64) - 1).astype(np.uint32)
+    nf = step != 0
+    cls = np.where(bad, np.uint32(31), cls)
     # bits 17 / 18: the read is included / its class is a known one (include/smcounter_hip.h: smc_class_bits)
     c = np.arange(32)
     inc = np.where(c < 6, c & 1, ((c - 6) & 7) >= 2).astype(np.uint32)

@@ -100,7 +100,7 @@ def unpack_shard(block: np.ndarray):
     ref, extras = json.loads(bytes(block[w_end:w_end + nb]).decode())
     ref = list(ref)
     base = list(BASE_ALLELES)
-    alleles = [base] * n
+    alleles = [list(base) for _ in range(n)]
     for k, t in extras.items():
         alleles[int(k)] = base + list(t)
     return wire, ref, alleles

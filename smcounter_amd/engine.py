@@ -110,8 +110,9 @@ class Engine(object):
         return np.frombuffer(raw, dtype, int(count))
 
     def trim(self):
-        """Give the cached device buffers (DevBuf) back to the runtime."""
+        """Give the cached device buffers (DevBuf) and the context's pool of plan blocks back to the runtime."""
         if self.ctx:
+            self.L.smc_pool_trim(self.ctx)
             for ptrs in self._spare.values():
                 for p in ptrs:
                     self.L.smc_mem_free(self.ctx, p)

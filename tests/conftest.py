@@ -25,8 +25,8 @@ def _native_built():
 
 def golden_files():
     import glob
-    # (the bam_*.npz fixtures hold BAM bytes, not pileups: tests/test_bam_golden.py)
-    return sorted(f for f in glob.glob(os.path.join(GOLDEN, "*.npz")) if not os.path.basename(f).startswith("bam_"))
+    # (the bam_*.npz fixtures hold BAM bytes and tools_*.npz the down-samplers' files, not pileups: test_bam_golden.py, test_tools.py)
+    return sorted(f for f in glob.glob(os.path.join(GOLDEN, "*.npz")) if not os.path.basename(f).startswith(("bam_", "tools_")))
 
 
 def load_golden(path):

@@ -386,6 +386,7 @@ def test_pack_words_matches_the_numpy_mirror_and_checks_the_slots(engine0):
         assert r_words["status"][5] & abi.ST_BAD_INPUT and r_planes["status"][5] & abi.ST_BAD_INPUT
         assert (np.delete(r_words["status"], 5) == 0).all()
         assert ((w[o:o + n] >> 27) == 31).sum() >= 1
+        assert np.array_equal(w, devplanes.pack_words_host(bad.meta, bad.frag, bad.loci))   # the mirror flags the same reads
 
 
 def test_full_size_properties(engine0):

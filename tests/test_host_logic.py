@@ -624,3 +624,44 @@ def test_bp_heads_bit_trick_against_a_loop_over_the_rows(tmp_path):
         cases.append((C, S, int(rng.integers(0, 2))))
     for C, S, c in cases:
         assert L.heads(C, S, c) == want(C, S, c), (hex(C), hex(S), c)
+
+
+def test_pack_words_host_applies_the_slot_contract():
+    """devplanes.pack_words_host flags what k_pack_words.inc flags (class 31 = no read class): a slot stepping by two, a first slot
+    that is not 0, a last slot that is not n_frag - 1 - at the offending read of that locus and nowhere else."""
+    from smcounter_amd import devplanes
+    cfg = synth.CONFIGS["C2"]
+    P = synth.params_for(cfg)
+    good = synth.generate_native(cfg, 0, 32, P)
+    w0 = devplanes.pack_words_host(good.meta, good.frag, good.loci)
+    o, n = good.read_off(5), int(good.loci["n_reads"][5])
+    assert ((w0 >> 27) != 31).all()
+    for case in range(3):
+        bad = synth.generate_native(cfg, 0, 32, P)
+        slot = bad.frag[o:o + n] & np.uint32(features.FRAG_SLOT_MASK)
+        cls = bad.frag[o:o + n] & ~np.uint32(features.FRAG_SLOT_MASK)
+        if case == 0:
+            slot[n // 2:] += 1
+            where = [n // 2, n - 1]                  # (the shifted tail also ends one past n_frag - 1)
+        elif case == 1:
+            slot += 1
+            where = [0, n - 1]
+        else:
+            bad.loci["n_frag"][5] += 1
+            where = [n - 1]
+        bad.frag[o:o + n] = cls | slot
+        w = devplanes.pack_words_host(bad.meta, bad.frag, bad.loci)
+        flagged = np.flatnonzero((w >> 27) == 31)
+        assert flagged.tolist() == [o + k for k in where]
+        keep = np.ones(len(w), bool)
+        keep[flagged] = False
+        assert np.array_equal(w[keep] & ~np.uint32(1 << 16), w0[keep] & ~np.uint32(1 << 16))
+
+
+def test_unpack_shard_gives_every_locus_its_own_allele_list():
+    from smcounter_amd.pileup import BASE_ALLELES
+    base = list(BASE_ALLELES)
+    block = dist.pack_shard(np.zeros(3, abi.WIRE_DTYPE), ["A", "C", "G"], [base, base + ["INS|A|AT"], base])
+    _, _, alleles = dist.unpack_shard(block)
+    alleles[0].append("x")
+    assert alleles[2] == base and alleles[1] == base + ["INS|A|AT"]
