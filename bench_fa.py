@@ -46,8 +46,8 @@ class AlignmentRun(object):
         self.A = A
         self.nl, self.ns, self.lo = A["nl"], A["n_slots"], int(A["start0"])
         self.reads = int(A["reads"])
-        up = lambda a: DevBuf(eng, a.nbytes + 64).upload(a.view(np.uint8).reshape(-1))
-        self.d_in = [up(A[k]) for k in ("aln", "cig", "seq", "qual", "loc")]
+        up = lambda a: DevBuf(eng, a.nbytes + 256).upload(a.view(np.uint8).reshape(-1))
+        self.d_in = [up(A[k]) for k in ("aln", "cig", "bq", "loc")]
         run_ref = synth.aln_ref_fetch(self.lo, self.lo + self.nl)
         self.d_ref = up(np.frombuffer(run_ref.encode(), np.uint8).copy())
         self.words = DevBuf(eng, 4 * (self.ns + 64))
@@ -58,7 +58,7 @@ class AlignmentRun(object):
         self.d_cnt = DevBuf(eng, 8)
         self.loc_host = np.ascontiguousarray(A["loc"])
         self.bi = abi.SmcBuildIn(self.d_in[0].data_ptr(), self.d_in[1].data_ptr(), self.d_in[2].data_ptr(), self.d_in[3].data_ptr(),
-                                 self.d_in[4].data_ptr(), self.d_ref.data_ptr(), self.lo, self.nl, A["n_bc"], A["n_pair"],
+                                 self.d_ref.data_ptr(), self.lo, self.nl, A["n_bc"], A["n_pair"],
                                  int(A["loc"]["n"].max()), len(A["aln"]), self.loc_host.ctypes.data)
         self.cp = abi.c_params(params)
         self.rows = DevBuf(eng, self.nl * abi.ROW_DTYPE.itemsize)
@@ -68,7 +68,7 @@ class AlignmentRun(object):
 
     def input_bytes(self):
         A = self.A
-        return int(A["aln"].nbytes + A["cig"].nbytes + A["seq"].nbytes + A["qual"].nbytes + A["loc"].nbytes)
+        return int(A["aln"].nbytes + A["cig"].nbytes + A["bq"].nbytes + A["loc"].nbytes)
 
     def needed_bytes(self):
         """What the walk that writes the read words has to move per launch: per pileup read one base + one quality in and

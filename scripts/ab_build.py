@@ -16,7 +16,8 @@ cfg = synth.CONFIGS[cfgname]
 run = fa_leg.AlignmentRun(eng, cfg, synth.params_for(cfg), n, 8)
 vp = ctypes.c_void_p
 H = []
-for path in libs:
+for spec in libs:
+    path = spec.split("@")[0]                                      # lib.so[@LDS_PAD]: SMC_BP_LDS_PAD for that entry's launches
     L = ctypes.CDLL(os.path.join(ROOT, "smcounter_amd", path))
     L.smc_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
     L.smc_last_error.restype = ctypes.c_char_p
@@ -27,10 +28,11 @@ for path in libs:
     L.smc_device_sync.argtypes = [vp]
     ctx = vp()
     assert L.smc_create(0, ctypes.byref(ctx)) == 0, L.smc_last_error()
-    H.append((path, L, ctx))
+    H.append((spec, L, ctx))
 
 
-def build(L, ctx):
+def build(L, ctx, spec=""):
+    os.environ["SMC_BP_LDS_PAD"] = spec.split("@")[1] if "@" in spec else "0"
     rc = L.smc_build_planes(ctx, ctypes.byref(run.cp), ctypes.byref(run.bi), 0, 0, run.words.data_ptr(), None, None, None, None,
                             run.uaux[0].data_ptr(), run.uaux[1].data_ptr(), run.uaux[2].data_ptr(), run.d_loci.data_ptr(),
                             run.d_x.data_ptr(), run.xcap, run.d_cnt.data_ptr(), None)
@@ -42,11 +44,11 @@ sig = {}
 res = {p: ([], []) for p, _, _ in H}
 for rnd in range(5):
     for path, L, ctx in H:
-        build(L, ctx); L.smc_device_sync(ctx)
+        build(L, ctx, path); L.smc_device_sync(ctx)
         L.smc_build_set_timing(ctx, REPS)
         t0 = time.perf_counter()
         for _ in range(REPS):
-            build(L, ctx)
+            build(L, ctx, path)
         L.smc_device_sync(ctx)
         wall = (time.perf_counter() - t0) / REPS * 1e3
         k_ms, k_n = ctypes.c_float(), ctypes.c_int32()

@@ -33,7 +33,7 @@ nl, ns = A["nl"], A["n_slots"]
 reads = int(A["loc"]["n"].sum())
 print("run: %d loci, %d alignments, %d pileup reads, %d barcodes, %d fragments" % (nl, len(A["aln"]), reads, A["n_bc"], A["n_pair"]))
 up = lambda a: DevBuf(eng, a.nbytes + 64).upload(a.view(np.uint8).reshape(-1))
-d_aln, d_cig, d_seq, d_qual, d_loc = up(A["aln"]), up(A["cig"]), up(A["seq"]), up(A["qual"]), up(A["loc"])
+d_aln, d_cig, d_bq, d_loc = up(A["aln"]), up(A["cig"]), up(A["bq"]), up(A["loc"])
 run_ref = ref_f.fetch(chrom, lo, hi).upper()
 d_ref = up(np.frombuffer(run_ref[:nl].encode().ljust(nl, b"\0"), np.uint8).copy())
 planes = [DevBuf(eng, 4 * ns)] + [DevBuf(eng, 4 * ns) if all_planes else None for k in range(4)]   # words, meta, umi, frag, dist
@@ -42,7 +42,7 @@ d_loci = DevBuf(eng, nl * LOCUS_DTYPE.itemsize)
 xcap = 4 * nl + 4096
 d_x = DevBuf(eng, 20 * xcap); d_cnt = DevBuf(eng, 8)
 loc_host = np.ascontiguousarray(A["loc"])
-bi = abi.SmcBuildIn(d_aln.data_ptr(), d_cig.data_ptr(), d_seq.data_ptr(), d_qual.data_ptr(), d_loc.data_ptr(), d_ref.data_ptr(),
+bi = abi.SmcBuildIn(d_aln.data_ptr(), d_cig.data_ptr(), d_bq.data_ptr(), d_loc.data_ptr(), d_ref.data_ptr(),
                     lo, nl, A["n_bc"], A["n_pair"], int(A["loc"]["n"].max()), len(A["aln"]), loc_host.ctypes.data)
 cp = abi.c_params(P)
 def call():

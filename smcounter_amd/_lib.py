@@ -93,7 +93,7 @@ def load(with_torch: bool = True):
     L.smc_event_elapsed_ms.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_float)]
     L.smc_event_destroy.argtypes = [vp]
     L.smc_event_destroy.restype = None
-    if L.smc_abi_version() != 4:
+    if L.smc_abi_version() != 5:
         raise SmcError("ABI version mismatch")
     if L.smc_row_size() != abi.ROW_DTYPE.itemsize or L.smc_locus_size() != 32 or L.smc_wire_row_size() != abi.WIRE_DTYPE.itemsize:
         raise SmcError("struct layout mismatch between include/smcounter_hip.h and smcounter_amd/abi.py")

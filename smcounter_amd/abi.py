@@ -30,7 +30,7 @@ class SmcParams(ctypes.Structure):
 
 class SmcBuildIn(ctypes.Structure):
     """smc_build_in (include/smcounter_hip.h): device pointers to a run's alignment arrays."""
-    _fields_ = [("aln", ctypes.c_void_p), ("cig", ctypes.c_void_p), ("seq", ctypes.c_void_p), ("qual", ctypes.c_void_p),
+    _fields_ = [("aln", ctypes.c_void_p), ("cig", ctypes.c_void_p), ("bq", ctypes.c_void_p),
                 ("loc", ctypes.c_void_p), ("refseq", ctypes.c_void_p), ("start0", ctypes.c_int32), ("n_loci", ctypes.c_int32),
                 ("n_bc", ctypes.c_int32), ("n_pair", ctypes.c_int32), ("max_depth", ctypes.c_int32), ("n_aln", ctypes.c_int32),
                 ("loc_host", ctypes.c_void_p)]

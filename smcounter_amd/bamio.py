@@ -633,7 +633,7 @@ class NativeBam(object):
 
     def alignments_run(self, chrom: str, lo: int, hi: int, max_reads: int, params, nthreads: int, host_array=None):
         """Host half of the device plane builder (smc_bam_alignments): the run's alignments as a structure of arrays -
-        dict(aln, cig, seq, qual, loc, nl, n_slots, n_bc, n_pair, status, reads).  The handle keeps the run's records:
+        dict(aln, cig, bq (+ its views seq, qual), loc, nl, n_slots, n_bc, n_pair, status, reads).  The handle keeps the run's records:
         `allele_key` / `barcode_name` refer to them until the next call.  `host_array(name, dtype, count)` (optional)
         provides the arrays (engine.Engine.pinned: page-locked staging memory, reused from run to run)."""
         import ctypes as C
@@ -644,10 +644,10 @@ class NativeBam(object):
         def alloc(ctx, n_aln, n_cig, n_seq, n_loci, out):
             got["aln"] = mk("aln", DEV_ALN_DTYPE, n_aln)
             got["cig"] = mk("cig", np.uint32, max(1, n_cig))
-            got["seq"] = mk("seq", np.uint8, max(1, n_seq))
-            got["qual"] = mk("qual", np.uint8, max(1, n_seq))
+            got["bq"] = mk("bq", np.uint8, 2 * max(1, n_seq))             # (letter, quality) byte pairs: smc_build_in.bq
+            got["seq"], got["qual"] = got["bq"][0::2], got["bq"][1::2]      # (views: the letters, the qualities)
             got["loc"] = mk("loc", DEV_LOCUS_DTYPE, n_loci)
-            for k, name in enumerate(("aln", "cig", "seq", "qual", "loc")):
+            for k, name in enumerate(("aln", "cig", "bq", "loc")):
                 out[k] = got[name].ctypes.data
         cb = _ALN_ALLOC(alloc)
         done, n_slots = C.c_int64(0), C.c_int64(0)

@@ -1197,11 +1197,12 @@ void smc_bam_planes_copy(void* h, uint32_t* umi_start, int32_t* n_keys, char* ke
 // entry per ALIGNMENT; everything per pileup read - which reads cover which locus, query position, allele, quality,
 // flags, read class, barcode / fragment ids by first appearance, the barcode-major order - is done by k_build_planes).
 //   aln[n_aln]   smc_dev_aln (36 B): position, end, CIGAR / sequence offsets, flags, MAPQ, run-wide barcode / read-name ids
-//   cig[n_cig]   the CIGAR words of those alignments; seq / qual[n_seq]: their bases (one ASCII letter each) and qualities
+//   cig[n_cig]   the CIGAR words of those alignments; bq[2 * n_seq]: their bases as (ASCII letter, quality) byte pairs
+//                (include/smcounter_hip.h: smc_build_in.bq - one stream, so that the device reads both with one fetch)
 //   loc[n_loci]  per locus: window [w0, w1) of alignments that can cover it, first padded slot, depth
 // status bits: 1 = an alignment has neither READ1 nor READ2 (pairOrder is carried over between pileup reads,
 // smCounter.py:359-362: that needs the sequential path), 2 = a field does not fit the packed record.
-// `alloc(ctx, n_aln, n_cig, n_seq, n_loci, out)` must fill out[0..4] with buffers for aln, cig, seq, qual, loc.
+// `alloc(ctx, n_aln, n_cig, n_seq, n_loci, out)` must fill out[0..3] with buffers for aln, cig, bq (2 * n_seq bytes), loc.
 // Returns pileup reads (unpadded) or < 0 as smc_bam_pileup.
 typedef void (*smc_aln_alloc)(void* ctx, int64_t n_aln, int64_t n_cig, int64_t n_seq, int64_t n_loci, void** out);
 int64_t smc_bam_alignments(void* h, const char* chrom, int64_t start0, int64_t end0, int64_t max_reads, double mismatch_thr,
@@ -1219,12 +1220,20 @@ int64_t smc_bam_alignments(void* h, const char* chrom, int64_t start0, int64_t e
     const int64_t span = end0 - start0;
     // one pass over the alignments: depth differences per position, and where each alignment's CIGAR words and bases go in the pools
     std::vector<int64_t> cov((size_t)span + 1, 0);
+    // Where an alignment's bases go in the pool: so that reference position start0 + 64 t (the first locus of the device builder's
+    // tile t) falls on a multiple of 64 bases = 128 bytes.  The 64 positions of an alignment under a tile are then ONE aligned
+    // 128-byte line of the pool (k_bp_emit2.inc reads them with eight 16-byte loads per row) instead of parts of two lines that the
+    // neighbouring tile fetches again; the gaps (31.5 bases on average) hold 'A' with quality 0 and are never under a covered locus.
     std::vector<uint32_t> offc(reads.size() + 1, 0), offs(reads.size() + 1, 0);
+    uint32_t pool_end = 0;
     for (size_t i = 0; i < reads.size(); ++i) {
         const Aln& a = reads[i];
         const int64_t lo = std::max<int64_t>(a.pos, start0), hi = std::min<int64_t>(a.end, end0);
         if (lo < hi) { ++cov[(size_t)(lo - start0)]; --cov[(size_t)(hi - start0)]; }
-        offc[i + 1] = offc[i] + a.cigar.n; offs[i + 1] = offs[i] + a.l_seq;
+        offc[i + 1] = offc[i] + a.cigar.n;
+        const uint32_t want = (uint32_t)((int64_t)a.pos - (int64_t)a.left_sp - start0) & 63u;
+        offs[i] = pool_end + ((want - pool_end) & 63u);
+        pool_end = offs[i] + a.l_seq;
     }
     int64_t nl = 0, total = 0, run = 0, slots = 0;
     std::vector<uint32_t> l_off, l_n;
@@ -1237,12 +1246,13 @@ int64_t smc_bam_alignments(void* h, const char* chrom, int64_t start0, int64_t e
         ++nl;
         if (total >= max_reads) break;
     }
-    const int64_t n_cig = offc[reads.size()], n_seq = offs[reads.size()];
-    void* bufs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    offs[reads.size()] = pool_end;
+    const int64_t n_cig = offc[reads.size()], n_seq = pool_end;
+    void* bufs[4] = {nullptr, nullptr, nullptr, nullptr};
     alloc(alloc_ctx, (int64_t)reads.size(), n_cig, n_seq, nl, bufs);
     smc_dev_aln* pa = (smc_dev_aln*)bufs[0]; uint32_t* pc = (uint32_t*)bufs[1];
-    uint8_t* ps = (uint8_t*)bufs[2]; uint8_t* pq = (uint8_t*)bufs[3]; smc_dev_locus* pl = (smc_dev_locus*)bufs[4];
-    if ((!reads.empty() && (!pa || !pc || !ps || !pq)) || (nl && !pl)) { b.err = "smc_bam_alignments: allocation callback returned no memory"; return -9; }
+    uint8_t* ps = (uint8_t*)bufs[2]; smc_dev_locus* pl = (smc_dev_locus*)bufs[3];
+    if ((!reads.empty() && (!pa || !pc || !ps)) || (nl && !pl)) { b.err = "smc_bam_alignments: allocation callback returned no memory"; return -9; }
     // the records and pools are filled by the threads
     std::atomic<int> st_bits(0);
     const auto t_p0 = std::chrono::steady_clock::now();
@@ -1269,11 +1279,15 @@ int64_t smc_bam_alignments(void* h, const char* chrom, int64_t start0, int64_t e
                 d.bc_gid = (uint32_t)a.bc_gid; d.pair_gid = (uint32_t)a.pair_gid;
                 uint32_t* c = pc + offc[i];
                 for (uint32_t w : a.cigar) *c++ = w;
-                uint8_t* sq = ps + offs[i];
+                uint8_t* sq = ps + 2 * (size_t)offs[i];                          // (letter, quality) pairs
+                for (size_t g = i ? (size_t)offs[i - 1] + reads[i - 1].l_seq : 0; g < (size_t)offs[i]; ++g) { ps[2 * g] = 'A'; ps[2 * g + 1] = 0; }   // (the gap before it)
                 const uint8_t* packed = a.seq.p;
-                for (uint32_t k = 0; k + 1 < a.l_seq; k += 2) { const uint8_t b2 = packed[k >> 1]; sq[k] = (uint8_t)CODE[b2 >> 4]; sq[k + 1] = (uint8_t)CODE[b2 & 15]; }
-                if (a.l_seq & 1) sq[a.l_seq - 1] = (uint8_t)CODE[packed[(a.l_seq - 1) >> 1] >> 4];
-                memcpy(pq + offs[i], a.qual.p, a.l_seq);
+                const uint8_t* ql = a.qual.p;
+                for (uint32_t k = 0; k + 1 < a.l_seq; k += 2) {
+                    const uint8_t b2 = packed[k >> 1];
+                    sq[2 * k] = (uint8_t)CODE[b2 >> 4]; sq[2 * k + 1] = ql[k]; sq[2 * k + 2] = (uint8_t)CODE[b2 & 15]; sq[2 * k + 3] = ql[k + 1];
+                }
+                if (a.l_seq & 1) { const uint32_t k = a.l_seq - 1; sq[2 * k] = (uint8_t)CODE[packed[k >> 1] >> 4]; sq[2 * k + 1] = ql[k]; }
             }
             if (st) st_bits.fetch_or(st);
         };

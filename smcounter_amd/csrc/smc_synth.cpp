@@ -324,6 +324,7 @@ int64_t smc_synth_alignments(const smc_synth_acfg* c, smc_aln_alloc alloc, void*
     std::vector<uint32_t> bc_gid((size_t)n_aln), pair_gid((size_t)n_aln), offc((size_t)n_aln + 1, 0), offs((size_t)n_aln + 1, 0);
     std::vector<int32_t> endp((size_t)n_aln);
     int32_t n_bc = 0, n_pair = 0;
+    uint32_t pool_end = 0;
     for (int64_t i = 0; i < n_aln; ++i) {
         const A& a = al[(size_t)i];
         if (bc_of[a.mol] < 0) bc_of[a.mol] = n_bc++;
@@ -331,7 +332,11 @@ int64_t smc_synth_alignments(const smc_synth_acfg* c, smc_aln_alloc alloc, void*
         if (pf < 0) pf = n_pair++;
         bc_gid[(size_t)i] = (uint32_t)bc_of[a.mol]; pair_gid[(size_t)i] = (uint32_t)pf;
         offc[(size_t)i + 1] = offc[(size_t)i] + (a.kind == 0 ? 1u : a.kind == 1 ? 2u : 3u);
-        offs[(size_t)i + 1] = offs[(size_t)i] + (uint32_t)a.len;
+        {   // the pool, laid out as the decoder lays it out (smc_bam_alignments): a tile's 64 positions of an alignment = one 128-byte line
+            const uint32_t want = (uint32_t)(a.pos - (a.kind == 1 ? a.clip : 0) - c->start0) & 63u;
+            offs[(size_t)i] = pool_end + ((want - pool_end) & 63u);
+            pool_end = offs[(size_t)i] + (uint32_t)a.len;
+        }
         // reference span: kind 1: len - clip; kind 2: len - 1 (one inserted base); kind 3: len + 2 (two deleted)
         endp[(size_t)i] = a.pos + (a.kind == 1 ? a.len - a.clip : a.kind == 2 ? a.len - 1 : a.kind == 3 ? a.len + 2 : a.len);
     }
@@ -342,11 +347,12 @@ int64_t smc_synth_alignments(const smc_synth_acfg* c, smc_aln_alloc alloc, void*
         const int64_t lo = std::max<int64_t>(al[(size_t)i].pos, s0), hi = std::min<int64_t>(endp[(size_t)i], e0);
         if (lo < hi) { ++cov[(size_t)(lo - s0)]; --cov[(size_t)(hi - s0)]; }
     }
-    void* bufs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    alloc(alloc_ctx, n_aln, (int64_t)offc[(size_t)n_aln], (int64_t)offs[(size_t)n_aln], c->n_loci, bufs);
+    void* bufs[4] = {nullptr, nullptr, nullptr, nullptr};
+    offs[(size_t)n_aln] = pool_end;
+    alloc(alloc_ctx, n_aln, (int64_t)offc[(size_t)n_aln], (int64_t)pool_end, c->n_loci, bufs);
     smc_dev_aln* pa = (smc_dev_aln*)bufs[0]; uint32_t* pc = (uint32_t*)bufs[1];
-    uint8_t* ps = (uint8_t*)bufs[2]; uint8_t* pq = (uint8_t*)bufs[3]; smc_dev_locus* pl = (smc_dev_locus*)bufs[4];
-    if (!pa || !pc || !ps || !pq || !pl) return -9;
+    uint8_t* ps = (uint8_t*)bufs[2]; smc_dev_locus* pl = (smc_dev_locus*)bufs[3];   // ps: (letter, quality) byte pairs, as the decoder writes them
+    if (!pa || !pc || !ps || !pl) return -9;
     int64_t slots = 0, total = 0, run = 0;
     {
         size_t w0 = 0, w1 = 0;
@@ -394,24 +400,25 @@ int64_t smc_synth_alignments(const smc_synth_acfg* c, smc_aln_alloc alloc, void*
                     else if (a.kind == 2) { cg[0] = (uint32_t)half << 4; cg[1] = 1u << 4 | 1u; cg[2] = (uint32_t)(a.len - half - 1) << 4; }
                     else { cg[0] = (uint32_t)half << 4; cg[1] = 2u << 4 | 2u; cg[2] = (uint32_t)(a.len - half) << 4; }
                     // bases: the reference under every query position (clips and the inserted base: a random letter), errors rare
-                    uint8_t* sq = ps + offs[(size_t)i];
-                    uint8_t* ql = pq + offs[(size_t)i];
+                    uint8_t* sq = ps + 2 * (size_t)offs[(size_t)i];
+                    uint8_t* ql = sq + 1;
+                    for (size_t g = i ? (size_t)offs[(size_t)i - 1] + (size_t)al[(size_t)i - 1].len : 0; g < (size_t)offs[(size_t)i]; ++g) { ps[2 * g] = 'A'; ps[2 * g + 1] = 0; }   // (the gap before it)
                     int64_t rp = a.pos + 1;                              // 1-based reference position of the next match
                     for (int q = 0; q < a.len; ++q) {
                         bool off_ref = (a.kind == 1 && q < a.clip) || (a.kind == 2 && q == half);
                         if (a.kind == 3 && q == half) rp += 2;           // the two deleted bases
-                        sq[q] = (uint8_t)(off_ref ? REF[g.below(4)] : REF[rp & 3]);
+                        sq[2 * q] = (uint8_t)(off_ref ? REF[g.below(4)] : REF[rp & 3]);
                         if (!off_ref) ++rp;
                     }
                     // sequencing errors by geometric skipping
                     if (c->p_err > 0) {
                         const double lg = log1p(-c->p_err);
                         for (int q = (int)(log(1.0 - g.uni()) / lg); q < a.len; q += 1 + (int)(log(1.0 - g.uni()) / lg))
-                            sq[q] = (uint8_t)REF[((sq[q] == 'A' ? 0 : sq[q] == 'C' ? 1 : sq[q] == 'G' ? 2 : 3) + 1 + (int)g.below(3)) & 3];
+                            sq[2 * q] = (uint8_t)REF[((sq[2 * q] == 'A' ? 0 : sq[2 * q] == 'C' ? 1 : sq[2 * q] == 'G' ? 2 : 3) + 1 + (int)g.below(3)) & 3];
                     }
                     for (int q = 0; q < a.len; q += 8) {
                         uint64_t w = g.next();
-                        for (int b = 0; b < 8 && q + b < a.len; ++b, w >>= 8) ql[q + b] = qlut[w & 255];
+                        for (int b = 0; b < 8 && q + b < a.len; ++b, w >>= 8) ql[2 * (q + b)] = qlut[w & 255];
                     }
                 }
             });

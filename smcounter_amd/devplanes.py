@@ -216,19 +216,18 @@ def build_run(A, L, eng, cp, params, chrom, lo, fasta, run_ref, planes, uaux, sl
     deepest = int(A["loc"]["n"].max()) if len(A["loc"]) else 0
     # (status bit 1 - an alignment flagged neither READ1 nor READ2 - no longer sends the run to the host builder: the walk's
     # exact path takes the previous pileup read's pairOrder, smCounter.py:359-362)
-    ok_status = 0 if os.environ.get("SMC_BP_EMIT") == "old" else 1       # (round 3's walk, kept for A/B runs, has no such path)
-    if (A["status"] & ~ok_status) != 0 or deepest > max_depth or slot_base + ns > cap or \
+    if (A["status"] & ~1) != 0 or deepest > max_depth or slot_base + ns > cap or \
             umi_base + ns + nl + 1 > cap + 8192:
         return None
-    up = lambda a: DevBuf(eng, a.nbytes + 64).upload(a.view(np.uint8).reshape(-1) if a.nbytes else np.zeros(4, np.uint8))
-    d_aln, d_cig, d_seq, d_qual, d_loc = up(A["aln"]), up(A["cig"]), up(A["seq"]), up(A["qual"]), up(A["loc"])
+    up = lambda a: DevBuf(eng, a.nbytes + 256).upload(a.view(np.uint8).reshape(-1) if a.nbytes else np.zeros(4, np.uint8))
+    d_aln, d_cig, d_bq, d_loc = up(A["aln"]), up(A["cig"]), up(A["bq"]), up(A["loc"])
     d_ref = up(np.frombuffer(run_ref[:nl].encode().ljust(nl, b"\0"), np.uint8).copy())
     d_loci = DevBuf(eng, nl * LOCUS_DTYPE.itemsize)
     xcap = 4 * nl + 4096
     d_x = DevBuf(eng, 20 * xcap)
     d_cnt = DevBuf(eng, 8)
     loc_host = np.ascontiguousarray(A["loc"])          # (the windows size the sort and the launch grids: read on the host)
-    bi = abi.SmcBuildIn(d_aln.data_ptr(), d_cig.data_ptr(), d_seq.data_ptr(), d_qual.data_ptr(), d_loc.data_ptr(), d_ref.data_ptr(),
+    bi = abi.SmcBuildIn(d_aln.data_ptr(), d_cig.data_ptr(), d_bq.data_ptr(), d_loc.data_ptr(), d_ref.data_ptr(),
                         lo, nl, A["n_bc"], A["n_pair"], deepest, len(A["aln"]), loc_host.ctypes.data)
     pp = [t.data_ptr() if t is not None else None for t in planes]     # [words, meta, umi, frag, dist]
     _lib.check(L.smc_build_planes(eng.ctx, ctypes.byref(cp), ctypes.byref(bi), slot_base, umi_base, pp[0], pp[1], pp[2], pp[3], pp[4],
@@ -246,7 +245,7 @@ def build_run(A, L, eng, cp, params, chrom, lo, fasta, run_ref, planes, uaux, sl
             raise PileupError("base quality > 126 at %s:%d-%d" % (chrom, lo + 1, lo + nl))
         return None
     lc = d_loci.download(LOCUS_DTYPE, nl)
-    for b in (d_aln, d_cig, d_seq, d_qual, d_loc, d_ref, d_loci, d_cnt):
+    for b in (d_aln, d_cig, d_bq, d_loc, d_ref, d_loci, d_cnt):
         b.free()                              # (back to the engine's spare list right away, not whenever the collector gets to them)
     # allele tables: the six fixed keys + what the kernel met, in the order it numbered them
     tables = [_BASE_TABLE] * nl                 # (shared, never written: a locus that met more alleles gets its own list)

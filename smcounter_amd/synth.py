@@ -497,7 +497,7 @@ def aln_ref_fetch(start: int, end: int) -> str:
 def generate_alignments(cfg: SynthConfig, n_loci: int = None, params=None, nthreads: int = 0, host_array=None,
                         p_ins_aln: float = 0.02, p_del_aln: float = 0.02, p_clip: float = 0.05):
     """A run of `n_loci` consecutive loci at cfg's depth shape (n_umi barcodes x rpb reads per locus) as the decoder would hand
-    it to smc_build_planes: dict(aln, cig, seq, qual, loc, nl, n_slots, n_bc, n_pair, status, reads, start0).
+    it to smc_build_planes: dict(aln, cig, bq (+ its views seq, qual), loc, nl, n_slots, n_bc, n_pair, status, reads, start0).
     `host_array(name, dtype, count)` may provide the arrays (page-locked staging)."""
     import ctypes as C
     import os
@@ -522,10 +522,10 @@ def generate_alignments(cfg: SynthConfig, n_loci: int = None, params=None, nthre
     def alloc(ctx, n_aln, n_cig, n_seq, nl, out):
         got["aln"] = mk("aln", DEV_ALN_DTYPE, n_aln)
         got["cig"] = mk("cig", np.uint32, max(1, n_cig))
-        got["seq"] = mk("seq", np.uint8, max(1, n_seq))
-        got["qual"] = mk("qual", np.uint8, max(1, n_seq))
+        got["bq"] = mk("bq", np.uint8, 2 * max(1, n_seq))             # (letter, quality) byte pairs: smc_build_in.bq
+        got["seq"], got["qual"] = got["bq"][0::2], got["bq"][1::2]      # (views: the letters, the qualities)
         got["loc"] = mk("loc", DEV_LOCUS_DTYPE, nl)
-        for k, name in enumerate(("aln", "cig", "seq", "qual", "loc")):
+        for k, name in enumerate(("aln", "cig", "bq", "loc")):
             out[k] = got[name].ctypes.data
     start0 = cfg.start_pos - 1                                     # the pileup generator's first locus, 0-based
     c = ACfg(n_loci, start0, cfg.n_umi, cfg.rpb, cfg.seed, cfg.p_overlap, cfg.p_err, p_ins_aln, p_del_aln, p_clip,
