@@ -63,6 +63,11 @@ const char* smc_bam_ds_info(void* h);
  * and :462-471 happens on the GPU.  Replaces, for this path, what the reference takes from pysam's AlignedSegment
  * objects. */
 /* (smc_dev_aln / smc_dev_locus: smcounter_hip.h - the HIP library reads them) */
+/* `alloc(ctx, n_aln, n_cig, n_seq, n_loci, out)` provides the four arrays: out[0] aln (n_aln x smc_dev_aln), out[1] the CIGAR pool
+ * (n_cig x uint32), out[2] the base pool as (ASCII letter, quality) byte pairs (2 x n_seq bytes: smc_build_in.bq - every alignment is
+ * placed so that reference position start0 + 64 t falls on pair 64 m, i.e. the builder's tile windows are aligned 128-byte lines; the
+ * gaps hold ('A', 0)), out[3] loc (n_loci x smc_dev_locus).  status bit 1: an alignment flagged neither READ1 nor READ2 (the device
+ * takes the previous pileup read's pairOrder), bit 2: a field does not fit the packed record (host builder). */
 typedef void (*smc_aln_alloc)(void* ctx, int64_t n_aln, int64_t n_cig, int64_t n_seq, int64_t n_loci, void** out);
 int64_t smc_bam_alignments(void* h, const char* chrom, int64_t start0, int64_t end0, int64_t max_reads, double mismatch_thr,
                            int nthreads, smc_aln_alloc alloc, void* alloc_ctx, int64_t* n_loci_done, int64_t* n_slots,
