@@ -1,0 +1,40 @@
+#!/bin/bash
+# Everything profiles/r04_* is assembled from, in one GPU call (every profiler run under its own timeout).
+# usage: bash scripts/collect_round4.sh [TAG]   (writes gpurun_out/TAG/, default r04final; then scripts/assemble_profiles_r04.py TAG)
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r04final}; mkdir -p $O
+cd $R
+timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
+timeout 600 bash scripts/shapes_perf.sh 7 > $O/shapes.txt 2>&1
+for spec in "2000 3000 60" "20000 1000 20" "500 58000 9"; do
+  set -- $spec
+  timeout 600 python3 scripts/e2e_perf.py $1 $2 $3 2>&1 | grep -v -E "amdgpu|smc_bam|collect_reads" > $O/e2e_$1.txt
+  timeout 300 python3 scripts/bp_perf.py $1 $2 $3 2>&1 | tail -2 > $O/bp_$1.txt
+done
+cd /tmp; export TMPDIR=/tmp; export PYTHONPATH=$R
+# kernel trace of the driver's command
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_under_trace.json 2>/dev/null
+find $O/kt -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
+python3 $R/scripts/kt_summary.py $O/kt > $O/kernel_trace_by_grid.txt
+# the step's kernels alone (the leg bench.py's headline times): trace by grid, timeline of one step, counters of the walk
+FA="-m bench_fa --config C3 --steps 6 --warmup 2 --blocks 1 --parity-loci 0"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fa_kt -- python3 $FA > $O/fa_under_trace.json 2>/dev/null
+python3 $R/scripts/kt_summary.py $O/fa_kt > $O/fa_kernels.txt
+python3 $R/scripts/kt_gaps.py $O/fa_kt > $O/fa_timeline.txt
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" \
+  "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_HIT_sum TCC_MISS_sum" \
+  "TCC_REQ_sum TCC_READ_sum TCC_WRITE_sum TCC_BUSY_avr" \
+  "TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum" \
+  "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
+  "SQ_BUSY_CYCLES SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --pmc $set --output-format csv -d $O/fa_p$i -- python3 $FA > /dev/null 2>&1 || echo "fa pass $i failed"
+done
+python3 $R/scripts/pmc_summary.py $O/fa_p* > $O/fa_pmc_summary.txt
+# kernel traces of two end-to-end runs
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_e2e -- python3 $R/scripts/e2e_perf.py 20000 1000 20 > /dev/null 2>&1
+python3 $R/scripts/kt_summary.py $O/kt_e2e > $O/e2e_kernels.txt
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_deep -- python3 $R/scripts/e2e_perf.py 500 58000 9 > /dev/null 2>&1
+python3 $R/scripts/kt_summary.py $O/kt_deep > $O/e2e_deep_kernels.txt
+find $O -name "*.csv" -size +300k -delete
+tail -3 $O/shapes.txt; head -14 $O/fa_kernels.txt; tail -3 $O/fa_timeline.txt; cat $O/e2e_500.txt | tail -12
