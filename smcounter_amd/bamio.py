@@ -763,13 +763,27 @@ def iter_pileup_batches_native(path: str, fasta, loci: Sequence[Tuple[str, str]]
 _ARENA_SLACK = 65536          # room for the overshoot of a batch's last locus and the 4-read padding (tests shrink it)
 
 
+def host_threads(per_node: int = 1) -> int:
+    """Threads the decoder's stages run on: SMC_HOST_THREADS, else the process's cores shared among the node's ranks, at most
+    HOST_THREADS_MAX.  A stage of a decode is a millisecond or two of work and ends when its LAST thread does: on every logical CPU
+    of a 256-thread host, one worker that the scheduler holds back (another process, a runtime thread) stalls the stage for a time
+    slice - measured: stages of 1.5 ms taking 25-57 ms now and then; with 48 threads the stages are as fast and the stalls gone."""
+    env = int(os.environ.get("SMC_HOST_THREADS", "0") or 0)
+    if env > 0:
+        return env
+    return max(1, min(HOST_THREADS_MAX, len(os.sched_getaffinity(0)) // max(1, per_node)))
+
+
+HOST_THREADS_MAX = 48
+
+
 def iter_device_batches_native(path: str, fasta, loci: Sequence[Tuple[str, str]], params, max_reads: int = 2_000_000,
                                nthreads: int = 0):
     """BAM -> `features.DeviceBatch` chunks in one native pass (decode, per-read features, barcode-major
     order, padding): equals extract_features(iter_pileup_batches(...)) chunk for chunk."""
     from .features import DeviceBatch
     bam = NativeBam(path)
-    nthreads = nthreads or len(os.sched_getaffinity(0))
+    nthreads = nthreads or host_threads()
     i, n = 0, len(loci)
     while i < n:
         first = i

@@ -104,7 +104,7 @@ def call_shard(args, params: VcParams, loci, device: int, early=None):
     # (one process per GPU: the ranks of a node share its cores for decoding)
     # (LOCAL_WORLD_SIZE: WORLD_SIZE also counts the ranks of other nodes, which do not share these cores)
     per_node = int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE", "1"))
-    nthreads = max(1, len(os.sched_getaffinity(0)) // max(1, per_node))
+    nthreads = bamio.host_threads(per_node)
     if decoder == "python":                                           # readable decoder, same batches
         batches = bamio.iter_pileup_batches(bamio.BamFile(args.bamFile), ref, loci, max_reads=args.batchReads)
     elif os.environ.get("SMC_PLANES", "device") == "host":             # planes built by the host threads, then uploaded
@@ -142,7 +142,7 @@ def call_shard_rows(args, params: VcParams, loci, device: int):
     ref = fasta.FastaFile(args.refGenome)
     eng = Engine(device)
     per_node = int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE", "1"))
-    nthreads = max(1, len(os.sched_getaffinity(0)) // max(1, per_node))
+    nthreads = bamio.host_threads(per_node)
     parts, refs, tables = [], [], []
     try:
         if os.environ.get("SMC_PLANES", "device") == "host":

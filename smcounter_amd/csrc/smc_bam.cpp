@@ -231,6 +231,8 @@ struct Bam {
     // last smc_bam_alignments result: the run's alignments (views into rec_data) and its barcode texts by run-wide id
     RawVec<Aln> d_reads;
     RawVec<Aln> parsed;                // (scratch of collect_reads, reused)
+    RawVec<uint64_t> it_key;           // (interning tables of collect_reads: hash, first record, the records' slots - reused, their pages stay)
+    RawVec<uint32_t> it_first, it_slot;
     std::vector<std::string> d_bc_names;
 
     bool load_block(uint64_t coff) {
@@ -499,22 +501,105 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, RawVe
         BlockStream bs(b, voff, b.io_threads, stop_hint);
         std::vector<std::pair<size_t, size_t>> recs;    // (offset of the body in bs.data, size)
         recs.reserve(bs.data.size() / 160 + 16);
-        for (;;) {
-            size_t rn;
-            const uint8_t* rp = bs.next_record(rn);
-            if (!rp) break;
-            // the walk is a chain of dependent loads, one cache line per record; records of a run are of similar size, so the
-            // headers of the next few are (mostly) where this one's size says - asked for ahead of the chain
-            {
-                const uint8_t* const lim = bs.data.data() + bs.data.size();
-                const size_t step = rn + 4;
-                for (int k = 3; k <= 6; ++k) { const uint8_t* q = rp - 4 + (size_t)k * step; if (q + 64 < lim) { __builtin_prefetch(q); __builtin_prefetch(q + 64); } }
+        int n_pieces = 0, n_rewalked = 0;               // (for SMC_BAM_TIMING)
+        // The record walk is a chain of dependent loads, one cache line per record (4 ms for the 310,000 records of a 58,000x run on
+        // one thread).  So: what a refill added is cut into pieces, every piece but the first GUESSES where a record starts (a
+        // position whose fields make sense as a record header, three records in a row) and walks from there on its own thread; then
+        // the pieces are joined in order - a piece counts only if the walk before it ended exactly where it began, otherwise its
+        // stretch is walked again from where the truth stands.  A wrong guess costs time, never a record.
+        {
+            const int n_ref = (int)b.ref_names.size();
+            struct Piece { size_t start = 0, stop = 0; bool ok = false, terminal = false; std::vector<std::pair<size_t, size_t>> r; };
+            // walk records from o while they start before `limit`; -> where it stopped (a record not consumed: incomplete, at / beyond
+            // the limit, or the terminal one)
+            auto walk = [&](size_t o, size_t limit, size_t avail, std::vector<std::pair<size_t, size_t>>& out, bool& terminal) -> size_t {
+                const uint8_t* d = bs.data.data();
+                terminal = false;
+                while (o < limit && o + 4 <= avail) {
+                    int32_t sz; memcpy(&sz, d + o, 4);
+                    if (sz < 0 || o + 4 + (size_t)sz > avail) break;                 // (cut by the end of what is inflated)
+                    if (sz < 8) { terminal = true; break; }                             // (malformed: the parser reports it)
+                    int32_t rt, rpos; memcpy(&rt, d + o + 4, 4); memcpy(&rpos, d + o + 8, 4);
+                    if (rt < 0 || rt > tid || (rt == tid && rpos >= end0)) { terminal = true; break; }
+                    if (rt == tid) out.emplace_back(o + 4, (size_t)sz);
+                    o += 4 + (size_t)sz;
+                }
+                return o;
+            };
+            auto plausible = [&](size_t o, size_t avail, size_t& next) -> bool {
+                const uint8_t* d = bs.data.data();
+                if (o + 36 > avail) return false;
+                int32_t sz, rt, rpos, lseq; memcpy(&sz, d + o, 4); memcpy(&rt, d + o + 4, 4); memcpy(&rpos, d + o + 8, 4); memcpy(&lseq, d + o + 20, 4);
+                const uint32_t lname = d[o + 12], ncig = (uint32_t)d[o + 16] | (uint32_t)d[o + 17] << 8;
+                if (sz < 32 || sz > (1 << 24) || o + 4 + (size_t)sz > avail) return false;
+                if (rt < -1 || rt >= n_ref || rpos < -1 || lseq < 0 || lname < 1) return false;
+                const uint64_t need = 32ull + lname + 4ull * ncig + ((uint64_t)lseq + 1) / 2 + (uint64_t)lseq;
+                if (need > (uint64_t)sz || d[o + 4 + 32 + lname - 1] != 0) return false;
+                next = o + 4 + (size_t)sz;
+                return true;
+            };
+            const int walk_test = getenv("SMC_BAM_WALK_TEST") ? atoi(getenv("SMC_BAM_WALK_TEST")) : 0;
+            bool done = false;
+            while (!done) {
+                const size_t avail = bs.data.size();
+                {   // a whole record at bs.pos?  (else: more data, or the end of the file)
+                    int32_t sz = -1;
+                    if (avail - bs.pos >= 4) memcpy(&sz, bs.data.data() + bs.pos, 4);
+                    if (!(sz >= 0 && bs.pos + 4 + (size_t)sz <= avail)) { if (!bs.refill()) break; continue; }
+                }
+                const size_t span = avail - bs.pos;
+                const int K = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, b.io_threads), span >> 18));
+                std::vector<Piece> pc((size_t)K);
+                Pool::get().run(K, b.io_threads, [&](int k) {
+                    Piece& P = pc[(size_t)k];
+                    const size_t nominal = bs.pos + span * (size_t)k / (size_t)K, limit = bs.pos + span * (size_t)(k + 1) / (size_t)K;
+                    size_t st = nominal;
+                    if (k > 0) {
+                        bool found = false;
+                        int skip = (walk_test == 2 && k % 3 == 1) ? 1 : 0;          // (tests: a guess that lies behind the first record of the piece)
+                        if (walk_test == 1 && (k & 1)) return;                        // (tests: no guess)
+                        for (; st < limit; ++st) {
+                            size_t n1, n2, n3;
+                            if (plausible(st, avail, n1) && plausible(n1, avail, n2) && plausible(n2, avail, n3)) { if (skip-- > 0) continue; found = true; break; }
+                        }
+                        if (!found) return;
+                    }
+                    P.start = st; P.ok = true;
+                    P.r.reserve((limit - st) / 200 + 16);
+                    P.stop = walk(st, limit, avail, P.r, P.terminal);
+                });
+                size_t cur = bs.pos;
+                bool stuck = false;                                                       // an incomplete record at `cur`: more data first
+                for (int k = 0; k < K && !done && !stuck; ++k) {
+                    Piece& P = pc[(size_t)k];
+                    const size_t limit = bs.pos + span * (size_t)(k + 1) / (size_t)K;
+                    ++n_pieces;
+                    if (!(P.ok && P.start == cur)) {
+                        ++n_rewalked;
+                        // the truth is not at the piece's start: walk up to it - or, without a usable guess, through the piece's stretch
+                        bool term = false;
+                        const size_t to = (P.ok && P.start > cur) ? P.start : limit;
+                        size_t got = walk(cur, to, avail, recs, term);
+                        if (term) { cur = got; done = true; break; }
+                        if (got < to) { cur = got; stuck = true; break; }
+                        cur = got;
+                        if (!(P.ok && P.start == cur)) {
+                            if (cur < limit) {
+                                got = walk(cur, limit, avail, recs, term);
+                                if (term) { cur = got; done = true; break; }
+                                if (got < limit) { cur = got; stuck = true; break; }
+                                cur = got;
+                            }
+                            continue;
+                        }
+                    }
+                    recs.insert(recs.end(), P.r.begin(), P.r.end());
+                    cur = P.stop;
+                    if (P.terminal) done = true;
+                    else if (P.stop < limit) stuck = true;
+                }
+                bs.pos = cur;
             }
-            int32_t rt, rpos;
-            memcpy(&rt, rp, 4); memcpy(&rpos, rp + 4, 4);
-            if (rt < 0 || rt > tid || (rt == tid && rpos >= end0)) break;
-            if (rt < tid) continue;
-            recs.emplace_back((size_t)(rp - bs.data.data()), rn);
         }
         // (the alignments are views into the inflated bytes: those move into the handle and live until the next run)
         b.rec_data.swap(bs.data);
@@ -560,32 +645,163 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, RawVe
         const auto tc2 = std::chrono::steady_clock::now();
         bool have_first = false, have_end = false;
         b.cur_end = -1; b.cur_voff_end = 0;
-        // 3a. which records the run keeps, the cursor checkpoints and the first malformed record - in file order (cheap)
+        // 3a. which records the run keeps, the cursor checkpoints and the first malformed record: stretches of the file in parallel,
+        // the stretches' first kept / first beyond-the-end / first malformed records combined in file order
         std::vector<uint8_t> keep(parsed.size(), 0);
         size_t n_keep = 0;
-        for (size_t pi = 0; pi < parsed.size(); ++pi) {
-            const Aln& a = parsed[pi];
-            if ((a.flag & 4) || a.cigar.empty()) continue;
-            if (a.end <= start0) continue;
-            if (!have_first) {                         // (its block_size word sits 4 bytes before the body)
+        {
+            const size_t NPk = parsed.size(), NONE = ~(size_t)0;
+            const int NK = (int)std::min<size_t>(256, NPk / 4096 + 1);
+            struct Part { size_t n, first, beyond, bad; };
+            std::vector<Part> part((size_t)NK, Part{0, NONE, NONE, NONE});
+            Pool::get().run(NK, b.io_threads, [&](int c) {
+                const size_t lo = NPk * (size_t)c / (size_t)NK, hi = NPk * (size_t)(c + 1) / (size_t)NK;
+                Part P{0, NONE, NONE, NONE};
+                for (size_t pi = lo; pi < hi; ++pi) {
+                    const Aln& a = parsed[pi];
+                    if ((a.flag & 4) || a.cigar.empty()) continue;
+                    if (a.end <= start0) continue;
+                    if (P.first == NONE) P.first = pi;
+                    if (P.beyond == NONE && a.end > end0) P.beyond = pi;
+                    if (a.c2 < 0 || a.l_seq == 0) { if (P.bad == NONE) P.bad = pi; continue; }
+                    keep[pi] = 1; ++P.n;
+                }
+                part[(size_t)c] = P;
+            });
+            size_t first = NONE, beyond = NONE, bad = NONE;
+            for (const Part& P : part) {
+                n_keep += P.n;
+                if (first == NONE) first = P.first;
+                if (beyond == NONE) beyond = P.beyond;
+                if (bad == NONE) bad = P.bad;
+            }
+            if (first != NONE) {                       // (its block_size word sits 4 bytes before the body)
                 have_first = true;
-                b.cur_tid = tid; b.cur_start = start0; b.cur_voff = bs.voffset_of(recs[pi].first - 4);
+                b.cur_tid = tid; b.cur_start = start0; b.cur_voff = bs.voffset_of(recs[first].first - 4);
             }
-            if (!have_end && a.end > end0) {           // first record a run starting at or after end0 can need
-                have_end = true;
-                b.cur_end = end0; b.cur_voff_end = bs.voffset_of(recs[pi].first - 4);
+            if (beyond != NONE) {                      // first record a run starting at or after end0 can need
+                have_end = true; (void)have_end;
+                b.cur_end = end0; b.cur_voff_end = bs.voffset_of(recs[beyond].first - 4);
             }
-            // qname -> barcode / read id (smCounter.py:320-325): <readid...>:<UMI>:<x>
-            if (a.c2 < 0) { b.err = "read name '" + std::string(a.qname) + "' has fewer than 3 ':' fields"; return -3; }
-            if (a.l_seq == 0) { b.err = "alignment " + std::string(a.qname) + " has no sequence"; return -4; }
-            keep[pi] = 1; ++n_keep;
+            if (bad != NONE) {
+                // qname -> barcode / read id (smCounter.py:320-325): <readid...>:<UMI>:<x>
+                const Aln& a = parsed[bad];
+                if (a.c2 < 0) { b.err = "read name '" + std::string(a.qname) + "' has fewer than 3 ':' fields"; return -3; }
+                b.err = "alignment " + std::string(a.qname) + " has no sequence"; return -4;
+            }
         }
-        // 3b. run-wide barcode / read-name ids by 64-bit hash, a hit confirmed against the first record that produced the id
-        // (memcmp) and a colliding hash resolved through a string map.  Sharded by hash over the threads: a shard owns its
-        // hashes, so ids are dense and exact whatever the thread count (they number DISTINCT strings; nothing downstream
-        // depends on their order: first-appearance numbering happens per locus).
         const auto tc2b = std::chrono::steady_clock::now();
+        auto tc2c = tc2b;
         int SH = 1;
+        auto bc_equal = [&](const Aln& o, const Aln& a) {
+            return (o.c1 - o.c2) == (a.c1 - a.c2) && memcmp(o.qname.data() + o.c2 + 1, a.qname.data() + a.c2 + 1, (size_t)(a.c1 - a.c2 - 1)) == 0;
+        };
+        auto pair_equal = [&](const Aln& o, const Aln& a) {
+            return o.c2 == a.c2 && bc_equal(o, a) && memcmp(o.qname.data(), a.qname.data(), (size_t)a.c2) == 0;
+        };
+        // 3b. run-wide barcode / read-name ids, numbered by first appearance in the file.  Every thread takes a stretch of the records
+        // and enters their 64-bit hashes into one shared open-addressing table (a compare-and-swap claims a slot, an atomic minimum
+        // keeps the slot's first record); a second pass confirms every record against its slot's first record (memcmp) and counts the
+        // first records per stretch; a prefix over the stretches gives the ids.  Two different strings with one hash - never seen -
+        // send the run to the sharded string-map path below.  Ids in file order are also what the device builder's sort likes: the
+        // ids under a tile's window then lie in a narrow range (k_bp_sort_seg narrows its keys to it).
+        bool collided = getenv("SMC_BAM_SHARDS") != nullptr;                    // (tests: the sharded path)
+        const size_t NP = parsed.size();
+        const int NCH = (int)std::min<size_t>(256, NP / 2048 + 1);
+        std::vector<uint32_t> nf_bc((size_t)NCH + 1, 0), nf_pair((size_t)NCH + 1, 0), n_kept((size_t)NCH + 1, 0);
+        if (!collided) {
+            size_t cap = 1024;
+            while (cap < 2 * n_keep + 16) cap <<= 1;
+            const size_t mask = cap - 1;
+            b.it_key.resize_uninit(2 * cap); b.it_first.resize_uninit(2 * cap); b.it_slot.resize_uninit(2 * NP + 2);
+            uint64_t* const key = b.it_key.p;
+            uint32_t* const first = b.it_first.p;
+            uint32_t* const slot = b.it_slot.p;
+            {
+                const int NZ = (int)std::min<size_t>(256, 2 * cap / 65536 + 1);
+                Pool::get().run(NZ, b.io_threads, [&](int c) {
+                    const size_t lo = 2 * cap * (size_t)c / (size_t)NZ, hi = 2 * cap * (size_t)(c + 1) / (size_t)NZ;
+                    memset(key + lo, 0, 8 * (hi - lo)); memset(first + lo, 0xFF, 4 * (hi - lo));
+                });
+            }
+            auto enter = [&](uint64_t h, size_t base, uint32_t pi) -> uint32_t {
+                const uint64_t k = h ? h : 1ull;
+                size_t i = (size_t)(k * 0x9E3779B97F4A7C15ull >> 20) & mask;
+                for (;;) {
+                    uint64_t cur = __atomic_load_n(&key[base + i], __ATOMIC_RELAXED);
+                    if (cur == 0ull && __atomic_compare_exchange_n(&key[base + i], &cur, k, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break;
+                    if (cur == k) break;
+                    i = (i + 1) & mask;
+                }
+                uint32_t f = __atomic_load_n(&first[base + i], __ATOMIC_RELAXED);
+                while (pi < f && !__atomic_compare_exchange_n(&first[base + i], &f, pi, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+                return (uint32_t)i;
+            };
+            Pool::get().run(NCH, b.io_threads, [&](int c) {
+                const size_t lo = NP * (size_t)c / (size_t)NCH, hi = NP * (size_t)(c + 1) / (size_t)NCH;
+                for (size_t pi = lo; pi < hi; ++pi) {
+                    if (!keep[pi]) continue;
+                    slot[pi] = enter(parsed[pi].h_bc, 0, (uint32_t)pi);
+                    slot[NP + pi] = enter(parsed[pi].h_pair, cap, (uint32_t)pi);
+                }
+            });
+            std::atomic<int> clash(0);
+            Pool::get().run(NCH, b.io_threads, [&](int c) {
+                const size_t lo = NP * (size_t)c / (size_t)NCH, hi = NP * (size_t)(c + 1) / (size_t)NCH;
+                uint32_t fb = 0, fp = 0, nk = 0;
+                bool bad = false;
+                for (size_t pi = lo; pi < hi; ++pi) {
+                    if (!keep[pi]) continue;
+                    ++nk;
+                    const Aln& a = parsed[pi];
+                    const uint32_t ob = first[slot[pi]], op = first[cap + slot[NP + pi]];
+                    if (ob == pi) ++fb; else if (!bc_equal(parsed[ob], a)) bad = true;
+                    if (op == pi) ++fp; else if (!pair_equal(parsed[op], a)) bad = true;
+                }
+                nf_bc[(size_t)c + 1] = fb; nf_pair[(size_t)c + 1] = fp; n_kept[(size_t)c + 1] = nk;
+                if (bad) clash.store(1);
+            });
+            collided = clash.load() != 0;
+            if (!collided) {
+                for (int c = 0; c < NCH; ++c) { nf_bc[(size_t)c + 1] += nf_bc[(size_t)c]; nf_pair[(size_t)c + 1] += nf_pair[(size_t)c]; n_kept[(size_t)c + 1] += n_kept[(size_t)c]; }
+                n_bc = (int)nf_bc[(size_t)NCH]; n_pair = (int)nf_pair[(size_t)NCH];
+                if (bc_names) bc_names->assign((size_t)n_bc, std::string());
+                // the first records take their ids (file order) ...
+                Pool::get().run(NCH, b.io_threads, [&](int c) {
+                    const size_t lo = NP * (size_t)c / (size_t)NCH, hi = NP * (size_t)(c + 1) / (size_t)NCH;
+                    int ib = (int)nf_bc[(size_t)c], ip = (int)nf_pair[(size_t)c];
+                    for (size_t pi = lo; pi < hi; ++pi) {
+                        if (!keep[pi]) continue;
+                        Aln& a = parsed[pi];
+                        if (first[slot[pi]] == pi) {
+                            if (bc_names) (*bc_names)[(size_t)ib] = std::string(a.qname.substr((size_t)a.c2 + 1, (size_t)(a.c1 - a.c2 - 1)));
+                            a.bc_gid = ib++;
+                        }
+                        if (first[cap + slot[NP + pi]] == pi) a.pair_gid = ip++;
+                    }
+                });
+                tc2c = std::chrono::steady_clock::now();
+                // ... the others copy theirs from their slot's first record; the kept records, in file order, are the run
+                const size_t base = reads.size();
+                reads.resize_uninit(base + n_keep);
+                Pool::get().run(NCH, b.io_threads, [&](int c) {
+                    const size_t lo = NP * (size_t)c / (size_t)NCH, hi = NP * (size_t)(c + 1) / (size_t)NCH;
+                    size_t o = base + n_kept[(size_t)c];
+                    for (size_t pi = lo; pi < hi; ++pi) {
+                        if (!keep[pi]) continue;
+                        Aln& a = parsed[pi];
+                        const uint32_t ob = first[slot[pi]], op = first[cap + slot[NP + pi]];
+                        if (ob != pi) a.bc_gid = parsed[ob].bc_gid;
+                        if (op != pi) a.pair_gid = parsed[op].pair_gid;
+                        reads[o++] = a;
+                    }
+                });
+            }
+        }
+        if (collided) {
+            // The earlier path: ids by 64-bit hash, a hit confirmed against the first record that produced the id (memcmp) and a
+            // colliding hash resolved through a string map.  Sharded by hash over the threads: a shard owns its hashes, so ids are
+            // dense and exact whatever the thread count (they number DISTINCT strings, shard by shard).
         while (SH < 64 && SH * 2 <= b.io_threads && (size_t)SH * 2048 < n_keep) SH *= 2;
         if (const char* e = getenv("SMC_BAM_SHARDS")) { SH = 1; while (SH < 64 && SH * 2 <= atoi(e)) SH *= 2; }   // (tests)
         // the kept records are first binned by shard (stretches of the file in parallel, a bin per stretch and shard; a
@@ -637,9 +853,6 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, RawVe
             std::unordered_map<std::string, int> bc_str, pair_str;     // only for colliding hashes
         };
         std::vector<Shard> shards((size_t)SH);
-        auto bc_equal = [&](const Aln& o, const Aln& a) {
-            return (o.c1 - o.c2) == (a.c1 - a.c2) && memcmp(o.qname.data() + o.c2 + 1, a.qname.data() + a.c2 + 1, (size_t)(a.c1 - a.c2 - 1)) == 0;
-        };
         auto intern = [&](int t) {
             Shard& S = shards[(size_t)t];
             {
@@ -704,7 +917,7 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, RawVe
                     (*bc_names)[(size_t)bc_off[(size_t)t] + k] = std::string(o.qname.substr((size_t)o.c2 + 1, (size_t)(o.c1 - o.c2 - 1)));
                 }
         }
-        const auto tc2c = std::chrono::steady_clock::now();
+        tc2c = std::chrono::steady_clock::now();
         {
             // the kept records, in file order, with the shard-local ids made run-wide (stretches in parallel)
             const uint64_t msk = (uint64_t)SH - 1;
@@ -730,14 +943,13 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, RawVe
                 }
             });
         }
-        const std::vector<int>& bc_rep = bc_off; const std::vector<int>& pair_rep = pair_off;    // (sizes below)
         n_bc = bc_off[(size_t)SH]; n_pair = pair_off[(size_t)SH];
-        (void)bc_rep; (void)pair_rep;
+        }
         if (getenv("SMC_BAM_TIMING")) {
             const auto tc3 = std::chrono::steady_clock::now();
             auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-            fprintf(stderr, "collect_reads: %zu records, %zu kept: inflate + boundaries %.1f ms (read %.1f, inflate %.1f), parse %.1f ms, keep %.1f ms, intern %.1f ms, gather %.1f ms (%zu KB inflated, %d shards)\n",
-                    recs.size(), reads.size(), ms(tc0, tc1), bs.t_read, bs.t_inflate, ms(tc1, tc2), ms(tc2, tc2b), ms(tc2b, tc2c), ms(tc2c, tc3), b.rec_data.size() >> 10, SH);
+            fprintf(stderr, "collect_reads: %zu records, %zu kept: inflate + boundaries %.1f ms (read %.1f, inflate %.1f), parse %.1f ms, keep %.1f ms, intern %.1f ms, gather %.1f ms (%zu KB inflated, %d shards; record walk: %d pieces, %d not joined at once)\n",
+                    recs.size(), reads.size(), ms(tc0, tc1), bs.t_read, bs.t_inflate, ms(tc1, tc2), ms(tc2, tc2b), ms(tc2b, tc2c), ms(tc2c, tc3), b.rec_data.size() >> 10, SH, n_pieces, n_rewalked);
         }
         if (!have_first) { b.cur_tid = tid; b.cur_start = start0; b.cur_voff = recs.empty() ? voff : bs.voffset_of(recs.back().first - 4); }
         if (!b.err.empty()) return -2;                  // corrupt / truncated BGZF
@@ -1224,16 +1436,42 @@ int64_t smc_bam_alignments(void* h, const char* chrom, int64_t start0, int64_t e
     // tile t) falls on a multiple of 64 bases = 128 bytes.  The 64 positions of an alignment under a tile are then ONE aligned
     // 128-byte line of the pool (k_bp_emit2.inc reads them with eight 16-byte loads per row) instead of parts of two lines that the
     // neighbouring tile fetches again; the gaps (31.5 bases on average) hold 'A' with quality 0 and are never under a covered locus.
+    // (stretches of the alignments in parallel: a stretch's bases start on a multiple of 64, so where its alignments go relative to
+    // that start does not depend on the stretches before it; the stretches' sizes are then summed up in order)
     std::vector<uint32_t> offc(reads.size() + 1, 0), offs(reads.size() + 1, 0);
     uint32_t pool_end = 0;
-    for (size_t i = 0; i < reads.size(); ++i) {
-        const Aln& a = reads[i];
-        const int64_t lo = std::max<int64_t>(a.pos, start0), hi = std::min<int64_t>(a.end, end0);
-        if (lo < hi) { ++cov[(size_t)(lo - start0)]; --cov[(size_t)(hi - start0)]; }
-        offc[i + 1] = offc[i] + a.cigar.n;
-        const uint32_t want = (uint32_t)((int64_t)a.pos - (int64_t)a.left_sp - start0) & 63u;
-        offs[i] = pool_end + ((want - pool_end) & 63u);
-        pool_end = offs[i] + a.l_seq;
+    const size_t NR = reads.size();
+    const int NS = (int)std::min<size_t>(128, NR / 8192 + 1);
+    std::vector<uint32_t> s_cig((size_t)NS + 1, 0), s_pool((size_t)NS + 1, 0);
+    std::vector<int32_t> s_maxend((size_t)NS, INT32_MIN);                      // (for the windows below: the largest end of a stretch)
+    {
+        Pool::get().run(NS, nthreads, [&](int c) {
+            const size_t lo_i = NR * (size_t)c / (size_t)NS, hi_i = NR * (size_t)(c + 1) / (size_t)NS;
+            uint32_t nc = 0, pe = 0;
+            int32_t me = INT32_MIN;
+            for (size_t i = lo_i; i < hi_i; ++i) {
+                const Aln& a = reads[i];
+                const int64_t lo = std::max<int64_t>(a.pos, start0), hi = std::min<int64_t>(a.end, end0);
+                if (lo < hi) { __atomic_fetch_add(&cov[(size_t)(lo - start0)], 1, __ATOMIC_RELAXED); __atomic_fetch_sub(&cov[(size_t)(hi - start0)], 1, __ATOMIC_RELAXED); }
+                offc[i] = nc; nc += a.cigar.n;
+                const uint32_t want = (uint32_t)((int64_t)a.pos - (int64_t)a.left_sp - start0) & 63u;
+                offs[i] = pe + ((want - pe) & 63u);
+                pe = offs[i] + a.l_seq;
+                me = std::max<int32_t>(me, (int32_t)a.end);
+            }
+            s_cig[(size_t)c + 1] = nc; s_pool[(size_t)c + 1] = pe; s_maxend[(size_t)c] = me;
+        });
+        for (int c = 0; c < NS; ++c) {
+            s_cig[(size_t)c + 1] += s_cig[(size_t)c];
+            s_pool[(size_t)c + 1] = ((s_pool[(size_t)c] + 63u) & ~63u) + s_pool[(size_t)c + 1];   // (the stretch starts on a multiple of 64)
+        }
+        Pool::get().run(NS, nthreads, [&](int c) {
+            const size_t lo_i = NR * (size_t)c / (size_t)NS, hi_i = NR * (size_t)(c + 1) / (size_t)NS;
+            const uint32_t bc = s_cig[(size_t)c], bp = (s_pool[(size_t)c] + 63u) & ~63u;
+            for (size_t i = lo_i; i < hi_i; ++i) { offc[i] += bc; offs[i] += bp; }
+        });
+        offc[NR] = s_cig[(size_t)NS];
+        pool_end = s_pool[(size_t)NS];
     }
     int64_t nl = 0, total = 0, run = 0, slots = 0;
     std::vector<uint32_t> l_off, l_n;
@@ -1296,13 +1534,27 @@ int64_t smc_bam_alignments(void* h, const char* chrom, int64_t start0, int64_t e
     const int st = st_bits.load();
     const auto t_p1 = std::chrono::steady_clock::now();
     // candidate window of every locus: [first alignment that ends behind it ... first alignment that starts behind it)
-    size_t w0 = 0, w1 = 0;
-    for (int64_t l = 0; l < nl; ++l) {
-        const int64_t p0 = start0 + l;
-        while (w0 < reads.size() && reads[w0].end <= p0) ++w0;
-        while (w1 < reads.size() && reads[w1].pos <= p0) ++w1;
-        pl[l].w0 = (uint32_t)w0; pl[l].w1 = (uint32_t)std::max(w0, w1);
-        pl[l].slot_off = l_off[(size_t)l]; pl[l].n = l_n[(size_t)l];
+    // (stretches of loci in parallel; a stretch finds its first two indices from scratch - the stretches of alignments above know
+    // their largest end, the positions are sorted - and then moves them along as the one-thread loop did; the packed records are read)
+    {
+        const int NL = (int)std::min<int64_t>(128, nl / 256 + 1);
+        Pool::get().run(NL, nthreads, [&](int c) {
+            const int64_t l_lo = nl * c / NL, l_hi = nl * (c + 1) / NL;
+            if (l_lo >= l_hi) return;
+            const int64_t pf = start0 + l_lo;
+            size_t w0 = NR, w1;
+            for (int k = 0; k < NS; ++k)
+                if ((int64_t)s_maxend[(size_t)k] > pf) { w0 = NR * (size_t)k / (size_t)NS; break; }   // the first stretch with an alignment that ends behind pf
+            while (w0 < NR && pa[w0].end <= pf) ++w0;
+            { size_t lo = 0, hi = NR; while (lo < hi) { const size_t mid = (lo + hi) / 2; if (pa[mid].pos <= pf) lo = mid + 1; else hi = mid; } w1 = lo; }
+            for (int64_t l = l_lo; l < l_hi; ++l) {
+                const int64_t p0 = start0 + l;
+                while (w0 < NR && pa[w0].end <= p0) ++w0;
+                while (w1 < NR && pa[w1].pos <= p0) ++w1;
+                pl[l].w0 = (uint32_t)w0; pl[l].w1 = (uint32_t)std::max(w0, w1);
+                pl[l].slot_off = l_off[(size_t)l]; pl[l].n = l_n[(size_t)l];
+            }
+        });
     }
     *n_loci_done = nl; *n_slots = slots; *n_bc_out = n_bc; *n_pair_out = n_pair; *status = st;
     if (getenv("SMC_BAM_TIMING")) {

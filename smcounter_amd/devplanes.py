@@ -102,7 +102,7 @@ def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], par
     from .engine import DevBuf
     L = eng.L
     bam = bamio.NativeBam(path)
-    nthreads = nthreads or len(os.sched_getaffinity(0))
+    nthreads = nthreads or bamio.host_threads()
     max_depth = L.smc_build_max_depth()
     cp = abi.c_params(params)
     i, n = 0, len(loci)

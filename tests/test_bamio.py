@@ -513,3 +513,44 @@ def test_two_decoders_on_two_threads_share_the_worker_pool(tmp_path):
         t.join()
     for k in (0, 1):
         assert len(got[k]) == 8 and all(x == alone[k] for x in got[k])
+
+
+def test_record_walk_in_pieces_equals_one_thread(tmp_path, monkeypatch):
+    """collect_reads finds the record boundaries of a refill in pieces, on threads: every piece but the first guesses a record start
+    and the pieces are joined only where one ended exactly at the next one's start.  A run of several MB (many pieces) with read
+    names, sequences and qualities of all lengths - and read names made of bytes that look like record headers - gives the same
+    alignments whatever the thread count; the pileup of a locus in its middle equals the Python decoder's."""
+    rng = np.random.Generator(np.random.PCG64(5))
+    L = 30000
+    ref = "".join(rng.choice(list("ACGT"), size=L))
+    recs = []
+    for i in range(24000):
+        pos = int(rng.integers(100, L - 400))
+        n = int(rng.integers(20, 250))
+        # a name whose bytes could be taken for the fixed fields of a record (small little-endian numbers, zeros are not allowed in names)
+        junk = "".join(chr(int(c)) for c in rng.integers(1, 8, size=int(rng.integers(0, 40))))
+        recs.append(dict(tid=0, pos=pos, qname="r%d%s:n%d:UMI%d:x" % (i, junk, i // 2, i % 97), flag=(0x40 if i % 2 == 0 else 0x80) | 1,
+                         mapq=60, cigar=[(0, n)], seq=ref[pos:pos + n], qual=rng.integers(2, 41, size=n).astype(np.uint8).tolist(), nm=0))
+    recs.sort(key=lambda r: r["pos"])
+    bam = str(tmp_path / "walk.bam")
+    bamio.write_bam(bam, [("chrW", L)], recs)
+    bamio.write_bai(bam)
+    P = VcParams()
+    runs = []
+    for nt, mode in ((1, "0"), (8, "0"), (8, "1"), (8, "2")):      # 1: every other piece has no guess; 2: every third guesses too far
+        monkeypatch.setenv("SMC_BAM_WALK_TEST", mode)
+        nb = bamio.NativeBam(bam)
+        A = nb.alignments_run("chrW", 500, 29000, 1 << 40, P, nt)
+        runs.append({k: np.array(A[k]).copy() if isinstance(A[k], np.ndarray) else A[k] for k in ("aln", "cig", "bq", "loc", "nl", "n_slots", "n_bc", "n_pair", "reads")})
+        nb.close()
+    a = runs[0]
+    for b in runs[1:]:
+        assert a["reads"] == b["reads"] and a["nl"] == b["nl"] and a["n_bc"] == b["n_bc"] == 97 and a["n_pair"] == b["n_pair"]
+        assert len(a["aln"]) == len(b["aln"]) > 20000
+        for k in ("aln", "cig", "loc"):
+            assert a[k].tobytes() == b[k].tobytes(), k
+        assert np.array_equal(a["bq"][:2 * int(a["aln"]["seq_off"][-1])], b["bq"][:2 * int(b["aln"]["seq_off"][-1])])
+    # depth of a locus in the middle against a count over the records
+    l = 15000 - 500
+    want = sum(1 for r in recs if r["pos"] <= 15000 < r["pos"] + r["cigar"][0][1])
+    assert int(a["loc"]["n"][l]) == want
