@@ -16,6 +16,7 @@
 
 #include "smcounter_hip.h"   // smc_locus: the descriptor smc_bam_planes fills
 
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -201,6 +202,8 @@ struct Aln {
 
 struct Bam {
     FILE* fh = nullptr;
+    const uint8_t* map = nullptr;      // the file, mapped (the block stream inflates straight from the page cache; nullptr: pread into `comp`)
+    size_t map_len = 0;
     std::string err;
     int io_threads = 1;                // threads inflating BGZF blocks in collect_reads
     ByteBuf rec_data;                  // inflated records of the last collect_reads (its alignments point into it)
@@ -382,18 +385,24 @@ struct BlockStream {
         want = std::min<size_t>(want, std::max<size_t>(1u << 20, (size_t)nthreads << 16));
         want = std::min<size_t>(std::max<size_t>(want, 1u << 18), 256u << 20);
         const auto tr0 = std::chrono::steady_clock::now();
-        if (!b.comp.resize(want)) { b.err = "out of memory"; eof = true; return false; }
         size_t got = 0;
-        while (got < want) {
-            const ssize_t r = pread(fileno(b.fh), b.comp.data() + got, want - got, (off_t)(next_coff + got));
-            if (r <= 0) break;
-            got += (size_t)r;
+        const uint8_t* cb = nullptr;
+        if (b.map && next_coff <= b.map_len) {                         // (a copy of 20 MB per 58,000x run saved: 2.5 ms)
+            cb = b.map + next_coff;
+            got = std::min<size_t>(want, b.map_len - (size_t)next_coff);
+        } else {
+            if (!b.comp.resize(want)) { b.err = "out of memory"; eof = true; return false; }
+            while (got < want) {
+                const ssize_t r = pread(fileno(b.fh), b.comp.data() + got, want - got, (off_t)(next_coff + got));
+                if (r <= 0) break;
+                got += (size_t)r;
+            }
+            cb = b.comp.data();
         }
         struct Blk { size_t c0, clen; uint32_t isize; size_t out_off; };
         std::vector<Blk> blks;
         size_t o = 0, total = 0;
         int past = 0;
-        const uint8_t* cb = b.comp.data();
         while (o + 18 <= got) {
             const uint8_t* hdr = cb + o;
             if (hdr[0] != 31 || hdr[1] != 139 || hdr[12] != 'B' || hdr[13] != 'C') { b.err = "not a BGZF block"; eof = true; break; }
@@ -1039,10 +1048,17 @@ int smc_bam_open(const char* path, void** out) {
     Bam* b = new Bam();
     b->fh = fopen(path, "rb");
     if (!b->fh) { delete b; return -1; }
+    if (!getenv("SMC_BAM_NO_MMAP")) {
+        struct stat sb;
+        if (fstat(fileno(b->fh), &sb) == 0 && sb.st_size > 0) {
+            void* m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fileno(b->fh), 0);
+            if (m != MAP_FAILED) { b->map = (const uint8_t*)m; b->map_len = (size_t)sb.st_size; }
+        }
+    }
     b->load_block(0);
     char magic[4];
     int32_t l_text, n_ref;
-    if (b->read(magic, 4) != 4 || memcmp(magic, "BAM\1", 4) != 0) { fclose(b->fh); delete b; return -2; }
+    if (b->read(magic, 4) != 4 || memcmp(magic, "BAM\1", 4) != 0) { if (b->map) munmap((void*)b->map, b->map_len); fclose(b->fh); delete b; return -2; }
     b->read(&l_text, 4);
     std::vector<char> text((size_t)l_text);
     b->read(text.data(), text.size());
@@ -1088,6 +1104,8 @@ int smc_bam_open(const char* path, void** out) {
 void smc_bam_close(void* h) {
     Bam* b = (Bam*)h;
     if (!b) return;
+    if (b->map) munmap((void*)b->map, b->map_len);
+    b->map = nullptr;
     if (b->fh) fclose(b->fh);
     b->fh = nullptr;
     {
