@@ -50,6 +50,9 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps each; value = the median block")
+    ap.add_argument("--slots", type=int, default=2,
+                    help="sets of output arrays (each with a stream of its own) consecutive steps alternate between: with 2 the builder "
+                         "of step i + 1 is enqueued while the locus kernels of step i run; 1: one step at a time")
     ap.add_argument("--config", default="C3", help="synthetic config (C2, C3, C5, C4); C3 is the metric's")
     ap.add_argument("--loci-per-gpu", type=int, default=0, help="override (default: the config's size)")
     ap.add_argument("--chunk", type=int, default=25000, help="loci generated / checked per chunk")
@@ -284,10 +287,13 @@ def main():
 
     # ---- the rank's run of alignments, resident in HBM
     t0 = time.time()
-    run = bench_fa.AlignmentRun(eng, cfg, params, n_mine, nthreads, shard=rank)
+    # (two sets of output arrays, each with a stream of its own: the builder of step i + 1 is enqueued while the locus kernels of
+    # step i run - as the runs of a BAM follow each other; --slots 1: one step at a time on one stream)
+    run = bench_fa.AlignmentRun(eng, cfg, params, n_mine, nthreads, shard=rank, slots=a.slots)
     torch.cuda.synchronize()
     t_build = time.time() - t0
     rows = torch.empty(n_mine * abi.ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    slot_streams = [run.stream_of(k) for k in range(a.slots)] if a.slots > 1 else None
 
     # N > 1: the rows of step i travel to rank 0 (RCCL, its own stream) while step i + 1 computes - two buffers per rank,
     # a buffer is reused only after its gather has completed (dist.RowPipeline).  What travels is the packed wire row
@@ -296,18 +302,21 @@ def main():
     packed = gather and a.wire == "packed"
     wire_bytes = L.smc_wire_row_size()
     if packed:
-        wires = [torch.empty(n_mine * wire_bytes, dtype=torch.uint8, device=dev) for _ in range(2)]
+        wires = [torch.empty(n_mine * wire_bytes, dtype=torch.uint8, device=dev) for _ in range(max(2, a.slots))]
 
-        def produce(buf):
-            run.step(rows=rows)
-            _lib.check(L.smc_pack_rows(eng.ctx, rows.data_ptr(), n_mine, buf.data_ptr(), None), "smc_pack_rows")
-        pipe = smcdist.RowPipeline(wires, collective=True)
+        def produce(buf, b=None):
+            import ctypes as _c
+            run.step(slot=b)                                         # (rows into the slot's own row buffer, on the slot's stream)
+            S = run.slots[run.last_slot]
+            sp = _c.c_void_p(S["stream"].cuda_stream) if S["stream"] is not None else None
+            _lib.check(L.smc_pack_rows(eng.ctx, S["rows"].data_ptr(), n_mine, buf.data_ptr(), sp), "smc_pack_rows")
+        pipe = smcdist.RowPipeline(wires, collective=True, streams=slot_streams)
     else:
-        bufs = [rows, torch.empty_like(rows)] if gather else [rows]
+        bufs = [rows] + [torch.empty_like(rows) for _ in range(max(2 if gather else 1, a.slots) - 1)]
 
-        def produce(buf):
-            run.step(rows=buf)
-        pipe = smcdist.RowPipeline(bufs, collective=gather)
+        def produce(buf, b=None):
+            run.step(rows=buf, slot=b)
+        pipe = smcdist.RowPipeline(bufs, collective=gather, streams=slot_streams)
 
     def step():
         pipe.step(produce)
@@ -344,7 +353,16 @@ def main():
     L.smc_build_set_timing(eng.ctx, 0)
     elapsed = sorted(blocks)[len(blocks) // 2]                   # the median block
     # the locus kernels of the same planes, timed alone with one more plan (outside the timed region)
-    plan = run.step(keep_plan=True, rows=rows)
+    if slot_streams is not None:
+        torch.cuda.set_stream(torch.cuda.default_stream(dev))
+    # one step at a time (every step on slot 0's stream): what a step takes when nothing of the next one runs beside it
+    torch.cuda.synchronize()
+    t_s = time.perf_counter()
+    for _ in range(a.steps):
+        run.step(rows=rows, slot=0)
+    torch.cuda.synchronize()
+    serial_ms = (time.perf_counter() - t_s) / a.steps * 1e3
+    plan = run.step(keep_plan=True, rows=rows, slot=0)
     torch.cuda.synchronize()
     plan.set_timing(8)
     for _ in range(8):
@@ -376,7 +394,8 @@ def main():
             "blocks": {"n": len(blocks), "steps_each": a.steps, "ms_per_step": [round(b / a.steps * 1e3, 4) for b in blocks],
                        "value_from": "median block", "spread_pct": round(100.0 * (max(blocks) - min(blocks)) / elapsed, 2)},
             "roofline": bench_fa.roofline_block(run, k_ms.value, k_n.value, a.config),
-            "step_breakdown": {"k_bp_emit2_ms": k_ms.value, "k_call_v2_ms": c_ms,
+            "step_breakdown": {"slots": a.slots, "ms_per_step_one_at_a_time": serial_ms,
+                               "k_bp_emit2_ms": k_ms.value, "k_call_v2_ms": c_ms,
                                "host_ms_per_step": {k: round(v / n_steps * 1e3, 3) for k, v in run.t.items() if k != "n"},
                                "pileup_reads_per_s": run.reads * a.steps / elapsed, "builder_status": status},
             "p_value_note": "C3 has no locus that reaches filterVariants (parity.loci_filtered 0): the p-value half of the metric is "
@@ -391,9 +410,8 @@ def main():
             out["cpu_baseline_single_process"] = cpu["python_single"]
             out["cpu_baseline_pool_chunked"] = cpu["python_pool_chunked"]
         if world == 1 and not a.no_parity:
-            run.step(rows=rows)
+            run.step(rows=rows, slot=0)
             torch.cuda.synchronize()
-            run.rows.free()
             run.rows = _TensorBuf(rows)
             out["parity"] = bench_fa.parity_full(run, nthreads, chunk=a.chunk)
     run.close()

@@ -32,7 +32,10 @@ class AlignmentRun(object):
     the read words).  `shard`: which stretch of the seeded config this rank takes (its loci start n_loci * shard further on,
     its molecules are drawn from another seed) - the weak-scaling input of rank `shard`."""
 
-    def __init__(self, eng, cfg, params, n_loci, nthreads, shard: int = 0):
+    def __init__(self, eng, cfg, params, n_loci, nthreads, shard: int = 0, slots: int = 1):
+        """`slots` > 1: consecutive steps alternate between that many sets of output arrays, each with a stream of its own - the
+        builder of step i + 1 is then enqueued while the locus kernels of step i still run (the host waits, inside
+        smc_plan_create_dev, only for the builder of the step it is issuing), as the runs of a BAM follow each other."""
         self.eng, self.params = eng, params
         if shard:
             cfg = dataclasses.replace(cfg, seed=cfg.seed + 7919 * shard, start_pos=cfg.start_pos + n_loci * shard)
@@ -50,18 +53,25 @@ class AlignmentRun(object):
         self.d_in = [up(A[k]) for k in ("aln", "cig", "bq", "loc")]
         run_ref = synth.aln_ref_fetch(self.lo, self.lo + self.nl)
         self.d_ref = up(np.frombuffer(run_ref.encode(), np.uint8).copy())
-        self.words = DevBuf(eng, 4 * (self.ns + 64))
-        self.uaux = [DevBuf(eng, 4 * (self.ns + self.nl + 64)) for _ in range(3)]
-        self.d_loci = DevBuf(eng, self.nl * LOCUS_DTYPE.itemsize)
         self.xcap = 4 * self.nl + 4096
-        self.d_x = DevBuf(eng, 20 * self.xcap)
-        self.d_cnt = DevBuf(eng, 8)
+        self.slots = []
+        for k in range(max(1, slots)):
+            S = {"words": DevBuf(eng, 4 * (self.ns + 64)), "uaux": [DevBuf(eng, 4 * (self.ns + self.nl + 64)) for _ in range(3)],
+                 "d_loci": DevBuf(eng, self.nl * LOCUS_DTYPE.itemsize), "d_x": DevBuf(eng, 20 * self.xcap), "d_cnt": DevBuf(eng, 8),
+                 "rows": DevBuf(eng, self.nl * abi.ROW_DTYPE.itemsize), "stream": None}
+            if slots > 1:
+                import torch
+                S["stream"] = torch.cuda.Stream(device=eng.device)
+            self.slots.append(S)
+        self.k = 0
+        S0 = self.slots[0]       # (what the callers that time the locus kernels alone, or check the rows, look at)
+        self.words, self.uaux, self.d_loci, self.d_x, self.d_cnt = S0["words"], S0["uaux"], S0["d_loci"], S0["d_x"], S0["d_cnt"]
         self.loc_host = np.ascontiguousarray(A["loc"])
         self.bi = abi.SmcBuildIn(self.d_in[0].data_ptr(), self.d_in[1].data_ptr(), self.d_in[2].data_ptr(), self.d_in[3].data_ptr(),
                                  self.d_ref.data_ptr(), self.lo, self.nl, A["n_bc"], A["n_pair"],
                                  int(A["loc"]["n"].max()), len(A["aln"]), self.loc_host.ctypes.data)
         self.cp = abi.c_params(params)
-        self.rows = DevBuf(eng, self.nl * abi.ROW_DTYPE.itemsize)
+        self.rows = S0["rows"]
         self.lc = np.empty(self.nl, LOCUS_DTYPE)
         self.host_plan = bool(os.environ.get("SMC_FA_HOST_PLAN"))      # (measurement: descriptors back to the host, smc_plan_create)
         self.t = {"build_issue": 0.0, "descriptors_d2h": 0.0, "plan_create": 0.0, "run_issue": 0.0, "n": 0}
@@ -77,24 +87,32 @@ class AlignmentRun(object):
         A = self.A
         return 2.0 * self.reads + 4.0 * self.ns + (36.0 + 32.0) * len(A["aln"]) + float(A["cig"].nbytes) + 36.0 * self.nl
 
-    def step(self, keep_plan=False, rows=None):
+    def step(self, keep_plan=False, rows=None, slot=None):
         """build -> descriptors -> plan -> run; everything the product path does between the decoder and the rows."""
         eng, L = self.eng, self.eng.L
+        if slot is None:
+            slot = self.k % len(self.slots)
+            self.k += 1
+        S = self.slots[slot]
+        self.last_slot = slot
+        st = S["stream"]
+        sp = ctypes.c_void_p(st.cuda_stream if st is not None else 0)
+        words, uaux, d_loci = S["words"], S["uaux"], S["d_loci"]
         t0 = time.perf_counter()
-        _lib.check(L.smc_build_planes(eng.ctx, ctypes.byref(self.cp), ctypes.byref(self.bi), 0, 0, self.words.data_ptr(), None, None,
-                                      None, None, self.uaux[0].data_ptr(), self.uaux[1].data_ptr(),
-                                      self.uaux[2].data_ptr(), self.d_loci.data_ptr(), self.d_x.data_ptr(), self.xcap,
-                                      self.d_cnt.data_ptr(), ctypes.c_void_p(0)), "smc_build_planes")
+        _lib.check(L.smc_build_planes(eng.ctx, ctypes.byref(self.cp), ctypes.byref(self.bi), 0, 0, words.data_ptr(), None, None,
+                                      None, None, uaux[0].data_ptr(), uaux[1].data_ptr(),
+                                      uaux[2].data_ptr(), d_loci.data_ptr(), S["d_x"].data_ptr(), self.xcap,
+                                      S["d_cnt"].data_ptr(), sp), "smc_build_planes")
         t1 = time.perf_counter()
         if self.host_plan:
-            self.d_loci.download(LOCUS_DTYPE, self.nl, out=self.lc)   # (behind the kernels on the default stream)
+            d_loci.download(LOCUS_DTYPE, self.nl, out=self.lc)        # (behind the kernels on the default stream)
             t2 = time.perf_counter()
             plan = eng.make_plan(self.lc)
         else:
             t2 = t1
-            plan = eng.make_plan_dev(self.d_loci, self.nl)            # binned where the descriptors are (waits for the builder)
+            plan = eng.make_plan_dev(d_loci, self.nl, stream=st)      # binned where the descriptors are (waits for the builder)
         t3 = time.perf_counter()
-        plan.run([self.words, self.uaux[0]], self.params, self.rows if rows is None else rows, stream=0)
+        plan.run([words, uaux[0]], self.params, S["rows"] if rows is None else rows, stream=st if st is not None else 0)
         t4 = time.perf_counter()
         T = self.t
         T["build_issue"] += t1 - t0; T["descriptors_d2h"] += t2 - t1; T["plan_create"] += t3 - t2; T["run_issue"] += t4 - t3; T["n"] += 1
@@ -105,9 +123,16 @@ class AlignmentRun(object):
     def status(self):
         return self.d_cnt.download(np.uint32, 2).tolist()
 
+    def stream_of(self, slot):
+        return self.slots[slot]["stream"]
+
     def close(self):
-        for b in self.d_in + [self.d_ref, self.words, self.d_loci, self.d_x, self.d_cnt, self.rows] + self.uaux:
+        for b in self.d_in + [self.d_ref]:
             b.free()
+        for S in self.slots:
+            for b in [S["words"], S["d_loci"], S["d_x"], S["d_cnt"], S["rows"]] + S["uaux"]:
+                if b is not None:
+                    b.free()
         self.A = None
 
 
@@ -172,12 +197,12 @@ def roofline_block(run: AlignmentRun, k_ms: float, k_n: int, cfg_name: str):
             "hbm_bytes_per_launch_pmc": rec["hbm_bytes_per_launch"] if rec else None}
 
 
-def run_leg(eng, cfg_name: str, n_loci: int, steps: int, warmup: int, blocks: int, nthreads: int, parity_loci: int = -1):
+def run_leg(eng, cfg_name: str, n_loci: int, steps: int, warmup: int, blocks: int, nthreads: int, parity_loci: int = -1, slots: int = 2):
     """The leg on one GPU, alone (scripts, `python3 -m bench_fa`); bench.py drives the same pieces itself."""
     cfg = synth.CONFIGS[cfg_name]
     params = synth.params_for(cfg)
     L = eng.L
-    run = AlignmentRun(eng, cfg, params, n_loci, nthreads)
+    run = AlignmentRun(eng, cfg, params, n_loci, nthreads, slots=slots)
     for _ in range(max(1, warmup)):
         run.step()
     L.smc_device_sync(eng.ctx)
@@ -196,8 +221,15 @@ def run_leg(eng, cfg_name: str, n_loci: int, steps: int, warmup: int, blocks: in
     k_ms, k_n = ctypes.c_float(), ctypes.c_int32()
     _lib.check(L.smc_build_kernel_ms(eng.ctx, ctypes.byref(k_ms), ctypes.byref(k_n)), "smc_build_kernel_ms")
     L.smc_build_set_timing(eng.ctx, 0)
+    # one step at a time (every step on slot 0's stream): what a step takes when nothing of the next one runs beside it
+    L.smc_device_sync(eng.ctx)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run.step(slot=0)
+    L.smc_device_sync(eng.ctx)
+    serial = (time.perf_counter() - t0) / steps * 1e3
     # the locus kernels of the same planes, timed alone with the last plan
-    plan = run.step(keep_plan=True)
+    plan = run.step(keep_plan=True, slot=0)
     L.smc_device_sync(eng.ctx)
     plan.set_timing(8)
     for _ in range(8):
@@ -211,6 +243,7 @@ def run_leg(eng, cfg_name: str, n_loci: int, steps: int, warmup: int, blocks: in
         "step": "smc_build_planes (read words) -> smc_plan_create_dev (binning on the device) -> smc_plan_run_words -> rows in HBM",
         "value": run.nl * steps / el, "unit": "loci/s", "ms_per_step": el / steps * 1e3,
         "blocks_ms_per_step": [round(t / steps * 1e3, 3) for t in times],
+        "slots": slots, "ms_per_step_one_at_a_time": serial,
         "pileup_reads_per_s": run.reads * steps / el,
         "host_ms_per_step": {k: round(v / n * 1e3, 3) for k, v in run.t.items() if k != "n"},
         "k_call_v2_ms": c_ms,
@@ -219,7 +252,7 @@ def run_leg(eng, cfg_name: str, n_loci: int, steps: int, warmup: int, blocks: in
         "generate_s": round(run.t_gen, 1),
     }
     if parity_loci:
-        run.step()
+        run.step(slot=0)
         L.smc_device_sync(eng.ctx)
         out["parity"] = parity_full(run, nthreads, 0 if parity_loci < 0 else parity_loci)
     run.close()
@@ -242,7 +275,9 @@ if __name__ == "__main__":
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--blocks", type=int, default=3)
     ap.add_argument("--parity-loci", type=int, default=-1, help="-1: every locus; 0: none; n: n loci as a first, a middle and a last stretch")
+    ap.add_argument("--slots", type=int, default=2, help="sets of output arrays + streams consecutive steps alternate between (1: one step at a time)")
     a = ap.parse_args()
     eng = Engine(0)
     cfg = synth.CONFIGS[a.config]
-    print(json.dumps(run_leg(eng, a.config, a.loci or cfg.n_loci, a.steps, a.warmup, a.blocks, len(os.sched_getaffinity(0)), a.parity_loci)))
+    print(json.dumps(run_leg(eng, a.config, a.loci or cfg.n_loci, a.steps, a.warmup, a.blocks, len(os.sched_getaffinity(0)), a.parity_loci,
+                             slots=a.slots)))

@@ -169,10 +169,14 @@ class RowPipeline(object):
     """Double-buffered "compute rows, gather them to rank 0" loop: the gather of step i (asynchronous collective)
     overlaps the computation of step i + 1; a row buffer is reused only after its gather has completed.
     `bufs`: this rank's row buffers (>= 1 tensors of equal size); `produce(buf)` enqueues the work that fills one.
-    With `world == 1` (no process group) it degenerates to calling `produce`."""
+    With `world == 1` (no process group) it degenerates to calling `produce`.
+    `streams` (optional, one per buffer): buffer b is produced on streams[b] - made the current stream BEFORE the wait for the
+    buffer's previous gather and left current for the gather that follows, so that both order against the stream that fills the
+    buffer; `produce(buf, b)` is then called with the buffer's index."""
 
-    def __init__(self, bufs, collective: bool, dst: int = 0):
+    def __init__(self, bufs, collective: bool, dst: int = 0, streams=None):
         self.bufs = list(bufs)
+        self.streams = list(streams) if streams else None
         self.collective = collective
         self.dst = dst
         self.pending = [None] * len(self.bufs)
@@ -190,9 +194,15 @@ class RowPipeline(object):
     def step(self, produce):
         b = self.n % len(self.bufs)
         self.n += 1
+        if self.streams is not None and self.streams[b] is not None:
+            import torch
+            torch.cuda.set_stream(self.streams[b])
         if self.pending[b] is not None:
             self.pending[b].wait()
-        produce(self.bufs[b])
+        if self.streams is not None:
+            produce(self.bufs[b], b)
+        else:
+            produce(self.bufs[b])
         if self.collective:
             import torch.distributed as dist
             if self.host_staged:

@@ -155,11 +155,12 @@ class Engine(object):
         return Plan(self, h, len(loci))
 
 
-    def make_plan_dev(self, d_loci, n_loci: int):
+    def make_plan_dev(self, d_loci, n_loci: int, stream=None):
         """The plan of a batch whose descriptors are in HBM (`d_loci`: DevBuf / tensor of smc_locus, e.g. what smc_build_planes
         wrote): binned on the device (smc_plan_create_dev), default stream.  `d_loci` must outlive the plan."""
         h = ctypes.c_void_p()
-        _lib.check(self.L.smc_plan_create_dev(self.ctx, d_loci.data_ptr(), int(n_loci), ctypes.c_void_p(0), ctypes.byref(h)),
+        sp = ctypes.c_void_p(stream.cuda_stream if stream is not None else 0)     # (a torch stream, or the default one)
+        _lib.check(self.L.smc_plan_create_dev(self.ctx, d_loci.data_ptr(), int(n_loci), sp, ctypes.byref(h)),
                    "smc_plan_create_dev")
         return Plan(self, h, int(n_loci))
 
