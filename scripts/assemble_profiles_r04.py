@@ -25,7 +25,9 @@ def last_json(path):
 
 for src, dst in (("bench.json", "r04_bench_C3_200k.json"), ("bench_under_trace.json", "r04_bench_under_trace.json"),
                  ("kernel_stats.csv", "r04_bench_kernel_stats.csv"), ("kernel_trace_by_grid.txt", "r04_bench_kernel_trace_by_grid.txt"),
-                 ("shapes.txt", "r04_other_shapes.txt")):
+                 ("shapes.txt", "r04_other_shapes.txt"), ("bench_2ranks_functional.json", "r04_bench_2ranks_one_gpu_functional.json")):
+    if not os.path.exists(os.path.join(O, src)):
+        continue
     shutil.copy(os.path.join(O, src), os.path.join(P, dst))
 bench = last_json(O + "/bench.json")
 fa_tr = last_json(O + "/fa_under_trace.json")

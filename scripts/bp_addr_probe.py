@@ -15,7 +15,7 @@ L = eng.L
 cfg = synth.CONFIGS["C3"]
 runs = [fa_leg.AlignmentRun(eng, cfg, synth.params_for(cfg), n, 8) for _ in range(copies)]
 for i, r in enumerate(runs):
-    print("copy %d: meta 0x%x frag 0x%x seq 0x%x qual 0x%x aln 0x%x" % (i, r.meta.ptr, r.frag.ptr, r.d_in[2].ptr, r.d_in[3].ptr, r.d_in[0].ptr))
+    print("copy %d: words 0x%x umi_start 0x%x bq 0x%x aln 0x%x" % (i, r.words.data_ptr(), r.uaux[0].data_ptr(), r.d_in[2].data_ptr(), r.d_in[0].data_ptr()))
 
 
 def timed(run, reps=6):

@@ -37,4 +37,6 @@ python3 $R/scripts/kt_summary.py $O/kt_e2e > $O/e2e_kernels.txt
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_deep -- python3 $R/scripts/e2e_perf.py 500 58000 9 > /dev/null 2>&1
 python3 $R/scripts/kt_summary.py $O/kt_deep > $O/e2e_deep_kernels.txt
 find $O -name "*.csv" -size +300k -delete
+cd $R; SMC_BENCH_SHARE_GPU=1 timeout 600 python bench.py --gpus 2 --steps 10 --warmup 3 --loci-per-gpu 50000 --no-other-configs --no-cpu-baseline > $O/bench_2ranks_functional.json 2>/dev/null
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1
 tail -3 $O/shapes.txt; head -14 $O/fa_kernels.txt; tail -3 $O/fa_timeline.txt; cat $O/e2e_500.txt | tail -12
