@@ -382,3 +382,68 @@ def test_plan_made_on_the_device_gives_the_same_rows(engine0, tmp_path):
         r_dev = p_dev.run_devbuf(rb.planes, prm).copy()
         p_host.close(); p_dev.close(); d_loci.free()
         assert r_host.tobytes() == r_dev.tobytes()
+
+
+def test_long_and_odd_cigars(engine0, tmp_path):
+    """k_bp_lin makes the general CIGARs' copies operation by operation, 16 lanes per alignment: alignments with 5 ... 70 operations
+    (more than 64: the exact path), a deletion straight after an insertion and the other way round, a reference skip next to an
+    indel, an insertion as the first and as the last aligned operation, hard + soft clips at both ends, operations of length 0 -
+    the same batch as the host builder, position by position."""
+    from smcounter_amd import devplanes
+    rng = np.random.default_rng(77)
+    L = 3000
+    ref = "".join(rng.choice(list("ACGT"), size=L))
+    fa_path = str(tmp_path / "odd.fa")
+    open(fa_path, "w").write(">chrO\n" + ref + "\n")
+
+    def build(pos, ops):
+        """ops: [(op, len)] -> (cigar, seq): bases follow the reference except inserted / clipped ones"""
+        seq, p = [], pos
+        for op, n in ops:
+            if op in (0, 7, 8):
+                seq.append(ref[p:p + n]); p += n
+            elif op in (1, 4):
+                seq.append("".join(rng.choice(list("ACGT"), size=n)))
+            elif op in (2, 3):
+                p += n
+        return ops, "".join(seq)
+
+    shapes = [
+        [(5, 3), (4, 4), (0, 30), (1, 2), (2, 3), (0, 20), (4, 3), (5, 2)],          # insertion then deletion
+        [(0, 25), (2, 2), (1, 3), (0, 25)],                                           # deletion then insertion
+        [(0, 20), (3, 40), (1, 1), (0, 20)],                                          # reference skip, then an insertion
+        [(0, 20), (1, 2), (3, 30), (0, 20)],                                          # insertion, then a reference skip
+        [(4, 2), (1, 3), (0, 40)],                                                    # an insertion as the first aligned operation
+        [(0, 40), (1, 3), (4, 2)],                                                    # ... and as the last
+        [(0, 10), (1, 0), (0, 10), (2, 0), (0, 30)],                                  # operations of length 0
+        [(0, 30), (2, 1), (0, 1), (2, 1), (0, 30)],                                   # a one-base match between two deletions
+    ]
+    recs = []
+    for i in range(1800):
+        pos = int(rng.integers(50, L - 800))
+        k = i % (len(shapes) + 3)
+        if k < len(shapes):
+            ops = shapes[k]
+        else:                                                                       # many small indels: 2 m + 1 operations
+            m = [2, 15, 35][k - len(shapes)]                                         # 5, 31 and 71 operations
+            ops = []
+            for j in range(m):
+                ops += [(0, int(rng.integers(3, 9))), ((1, int(rng.integers(1, 3))) if j % 2 else (2, int(rng.integers(1, 4))))]
+            ops.append((0, 6))
+        cigar, seq = build(pos, ops)
+        recs.append(dict(tid=0, pos=pos, qname="r%d:n%d:BC%03d:y" % (i, i // 2, i % 61), flag=(0x41 if i % 2 == 0 else 0x91),
+                         mapq=60, cigar=cigar, seq=seq, qual=rng.choice([12, 25, 30, 37], size=len(seq)).astype(np.uint8).tolist(),
+                         nm=int(rng.integers(0, 3))))
+    recs.sort(key=lambda r: r["pos"])
+    bam = str(tmp_path / "odd.bam")
+    bamio.write_bam(bam, [("chrO", L)], recs)
+    bamio.write_bai(bam)
+    fa = fasta.FastaFile(fa_path)
+    loci = [("chrO", str(p)) for p in range(40, L - 300)]
+    P = VcParams(mtDepth=100000, rpb=2.0, hpLen=8)
+    host = list(bamio.iter_device_batches_native(bam, fa, loci, P, max_reads=64_000_000))
+    dev = list(devplanes.iter_resident_batches(bam, fa, loci, P, engine0, max_reads=64_000_000))
+    assert len(host) == len(dev) == 1
+    (_, hb), (_, rb) = host[0], dev[0]
+    assert rb.n_device_runs >= 1 and rb.n_host_runs == 0
+    _same_batch(rb, hb)
