@@ -382,7 +382,12 @@ struct BlockStream {
         size_t want = 8u << 20;
         if (soft_stop != ~0ull) want = soft_stop > next_coff ? (size_t)(soft_stop - next_coff) + (3u << 16) : (3u << 16);
         // (no further per refill than the threads can share: a consumer that finds its last record early stops refilling)
-        want = std::min<size_t>(want, std::max<size_t>(1u << 20, (size_t)nthreads << 16));
+        {
+            // (128 KB of compressed bytes per thread and refill: every refill is two rounds of the pool - inflate, record walk -, and
+            // at 64 KB the 58,000x run's seven refills cost 2 ms more than its four do)
+            static const int sh = getenv("SMC_BAM_REFILL_SHIFT") ? atoi(getenv("SMC_BAM_REFILL_SHIFT")) : 17;
+            want = std::min<size_t>(want, std::max<size_t>(1u << 20, (size_t)nthreads << sh));
+        }
         want = std::min<size_t>(std::max<size_t>(want, 1u << 18), 256u << 20);
         const auto tr0 = std::chrono::steady_clock::now();
         size_t got = 0;
