@@ -50,6 +50,9 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps each; value = the median block")
+    ap.add_argument("--place", type=int, default=14,
+                    help="extra allocations of the read words tried at set-up, the fastest kept: which allocation holds the array moves "
+                         "the walk's time by up to 10 %% (DESIGN.md section 8); 0: take what comes")
     ap.add_argument("--slots", type=int, default=2,
                     help="sets of output arrays (each with a stream of its own) consecutive steps alternate between: with 2 the builder "
                          "of step i + 1 is enqueued while the locus kernels of step i run; 1: one step at a time")
@@ -289,7 +292,7 @@ def main():
     t0 = time.time()
     # (two sets of output arrays, each with a stream of its own: the builder of step i + 1 is enqueued while the locus kernels of
     # step i run - as the runs of a BAM follow each other; --slots 1: one step at a time on one stream)
-    run = bench_fa.AlignmentRun(eng, cfg, params, n_mine, nthreads, shard=rank, slots=a.slots)
+    run = bench_fa.AlignmentRun(eng, cfg, params, n_mine, nthreads, shard=rank, slots=a.slots, place=a.place)
     torch.cuda.synchronize()
     t_build = time.time() - t0
     rows = torch.empty(n_mine * abi.ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev)
@@ -400,7 +403,7 @@ def main():
                     "bytes_per_step": 16.0 * run.reads + 360.0 * run.nl,
                     "achieved": (16.0 * run.reads + 360.0 * run.nl) / (elapsed / a.steps) / 1e9, "unit": "GB/s",
                     "frac": (16.0 * run.reads + 360.0 * run.nl) / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS}}),
-            "step_breakdown": {"slots": a.slots, "ms_per_step_one_at_a_time": serial_ms,
+            "step_breakdown": {"slots": a.slots, "ms_per_step_one_at_a_time": serial_ms, "placement": run.placement,
                                "k_bp_emit2_ms": k_ms.value, "k_call_v2_ms": c_ms,
                                "host_ms_per_step": {k: round(v / n_steps * 1e3, 3) for k, v in run.t.items() if k != "n"},
                                "pileup_reads_per_s": run.reads * a.steps / elapsed, "builder_status": status},

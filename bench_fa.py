@@ -32,10 +32,15 @@ class AlignmentRun(object):
     the read words).  `shard`: which stretch of the seeded config this rank takes (its loci start n_loci * shard further on,
     its molecules are drawn from another seed) - the weak-scaling input of rank `shard`."""
 
-    def __init__(self, eng, cfg, params, n_loci, nthreads, shard: int = 0, slots: int = 1):
+    def __init__(self, eng, cfg, params, n_loci, nthreads, shard: int = 0, slots: int = 1, place: int = 0):
         """`slots` > 1: consecutive steps alternate between that many sets of output arrays, each with a stream of its own - the
         builder of step i + 1 is then enqueued while the locus kernels of step i still run (the host waits, inside
-        smc_plan_create_dev, only for the builder of the step it is issuing), as the runs of a BAM follow each other."""
+        smc_plan_create_dev, only for the builder of the step it is issuing), as the runs of a BAM follow each other.
+        `place` > 0: WHICH ALLOCATION holds the read words moves the walk's time by up to 10 % (1.33 / 1.38 / 1.46 ms
+        for three allocations of the same 2.4 GB in one process, the same from launch to launch; offsets inside an allocation do not
+        matter).  The arrays of a resident run are allocated once and used step after step, so the run tries `place` more
+        allocations (behind spacer allocations of different sizes: allocations made back to back tend to be alike), times the walk
+        into each - set-up, outside every timed region - and keeps the fastest."""
         self.eng, self.params = eng, params
         if shard:
             cfg = dataclasses.replace(cfg, seed=cfg.seed + 7919 * shard, start_pos=cfg.start_pos + n_loci * shard)
@@ -75,6 +80,48 @@ class AlignmentRun(object):
         self.lc = np.empty(self.nl, LOCUS_DTYPE)
         self.host_plan = bool(os.environ.get("SMC_FA_HOST_PLAN"))      # (measurement: descriptors back to the host, smc_plan_create)
         self.t = {"build_issue": 0.0, "descriptors_d2h": 0.0, "plan_create": 0.0, "run_issue": 0.0, "n": 0}
+        self.placement = None
+        if place > 0:
+            self._place(place)
+            self.words = self.slots[0]["words"]
+
+    def _walk_ms(self, reps: int = 3) -> float:
+        eng, L = self.eng, self.eng.L
+        self.step(slot=0)
+        L.smc_device_sync(eng.ctx)
+        _lib.check(L.smc_build_set_timing(eng.ctx, reps), "smc_build_set_timing")
+        for _ in range(reps):
+            self.step(slot=0)
+        L.smc_device_sync(eng.ctx)
+        k_ms, k_n = ctypes.c_float(), ctypes.c_int32()
+        _lib.check(L.smc_build_kernel_ms(eng.ctx, ctypes.byref(k_ms), ctypes.byref(k_n)), "smc_build_kernel_ms")
+        L.smc_build_set_timing(eng.ctx, 0)
+        return float(k_ms.value)
+
+    def _place(self, extra: int):
+        eng = self.eng
+        cands, spacers = [S["words"] for S in self.slots], []
+        for i in range(extra):
+            mb = (37, 301, 1024, 2500, 150, 4097, 611, 1777)[i % 8]
+            spacers.append(DevBuf(eng, (mb << 20) + 4096))
+            cands.append(DevBuf(eng, 4 * (self.ns + 64)))
+        ms = []
+        for w in cands:
+            self.slots[0]["words"] = w
+            ms.append(self._walk_ms())
+        order = sorted(range(len(cands)), key=lambda i: ms[i])
+        for k, S in enumerate(self.slots):
+            S["words"] = cands[order[k]]
+        for i in order[len(self.slots):]:
+            cands[i].free()
+        for sp in spacers:
+            sp.free()
+        eng.trim()                                  # (the candidates that lost go back to the runtime, not to the engine's spare list)
+        self.placement = {"walk_ms_by_allocation": [round(x, 3) for x in ms], "kept": [round(ms[i], 3) for i in order[:len(self.slots)]],
+                          "note": "which allocation holds the read words moves the walk's time (DESIGN.md section 8); candidates are timed "
+                                  "at set-up, outside every timed region, and the fastest kept"}
+        for k in self.t:
+            self.t[k] = 0
 
     def input_bytes(self):
         A = self.A
@@ -197,12 +244,13 @@ def roofline_block(run: AlignmentRun, k_ms: float, k_n: int, cfg_name: str):
             "hbm_bytes_per_launch_pmc": rec["hbm_bytes_per_launch"] if rec else None}
 
 
-def run_leg(eng, cfg_name: str, n_loci: int, steps: int, warmup: int, blocks: int, nthreads: int, parity_loci: int = -1, slots: int = 2):
+def run_leg(eng, cfg_name: str, n_loci: int, steps: int, warmup: int, blocks: int, nthreads: int, parity_loci: int = -1, slots: int = 2,
+            place: int = 14):
     """The leg on one GPU, alone (scripts, `python3 -m bench_fa`); bench.py drives the same pieces itself."""
     cfg = synth.CONFIGS[cfg_name]
     params = synth.params_for(cfg)
     L = eng.L
-    run = AlignmentRun(eng, cfg, params, n_loci, nthreads, slots=slots)
+    run = AlignmentRun(eng, cfg, params, n_loci, nthreads, slots=slots, place=place)
     for _ in range(max(1, warmup)):
         run.step()
     L.smc_device_sync(eng.ctx)
@@ -243,7 +291,7 @@ def run_leg(eng, cfg_name: str, n_loci: int, steps: int, warmup: int, blocks: in
         "step": "smc_build_planes (read words) -> smc_plan_create_dev (binning on the device) -> smc_plan_run_words -> rows in HBM",
         "value": run.nl * steps / el, "unit": "loci/s", "ms_per_step": el / steps * 1e3,
         "blocks_ms_per_step": [round(t / steps * 1e3, 3) for t in times],
-        "slots": slots, "ms_per_step_one_at_a_time": serial,
+        "slots": slots, "ms_per_step_one_at_a_time": serial, "placement": run.placement,
         "pileup_reads_per_s": run.reads * steps / el,
         "host_ms_per_step": {k: round(v / n * 1e3, 3) for k, v in run.t.items() if k != "n"},
         "k_call_v2_ms": c_ms,
@@ -276,8 +324,9 @@ if __name__ == "__main__":
     ap.add_argument("--blocks", type=int, default=3)
     ap.add_argument("--parity-loci", type=int, default=-1, help="-1: every locus; 0: none; n: n loci as a first, a middle and a last stretch")
     ap.add_argument("--slots", type=int, default=2, help="sets of output arrays + streams consecutive steps alternate between (1: one step at a time)")
+    ap.add_argument("--place", type=int, default=14, help="extra allocations of the read words tried at set-up, the fastest kept (0: none)")
     a = ap.parse_args()
     eng = Engine(0)
     cfg = synth.CONFIGS[a.config]
     print(json.dumps(run_leg(eng, a.config, a.loci or cfg.n_loci, a.steps, a.warmup, a.blocks, len(os.sched_getaffinity(0)), a.parity_loci,
-                             slots=a.slots)))
+                             slots=a.slots, place=a.place)))
