@@ -50,7 +50,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps each; value = the median block")
-    ap.add_argument("--place", type=int, default=14,
+    ap.add_argument("--place", type=int, default=30,
                     help="extra allocations of the read words tried at set-up, the fastest kept: which allocation holds the array moves "
                          "the walk's time by up to 10 %% (DESIGN.md section 8); 0: take what comes")
     ap.add_argument("--slots", type=int, default=2,

@@ -101,8 +101,12 @@ class AlignmentRun(object):
     def _place(self, extra: int):
         eng = self.eng
         cands, spacers = [S["words"] for S in self.slots], []
+        budget = 110e9                                # bytes the candidates and their spacers may take together (of 288 GB)
         for i in range(extra):
             mb = (37, 301, 1024, 2500, 150, 4097, 611, 1777)[i % 8]
+            budget -= (mb << 20) + 4.0 * (self.ns + 64)
+            if budget < 0:
+                break
             spacers.append(DevBuf(eng, (mb << 20) + 4096))
             cands.append(DevBuf(eng, 4 * (self.ns + 64)))
         ms = []
@@ -245,7 +249,7 @@ def roofline_block(run: AlignmentRun, k_ms: float, k_n: int, cfg_name: str):
 
 
 def run_leg(eng, cfg_name: str, n_loci: int, steps: int, warmup: int, blocks: int, nthreads: int, parity_loci: int = -1, slots: int = 2,
-            place: int = 14):
+            place: int = 30):
     """The leg on one GPU, alone (scripts, `python3 -m bench_fa`); bench.py drives the same pieces itself."""
     cfg = synth.CONFIGS[cfg_name]
     params = synth.params_for(cfg)
@@ -324,7 +328,7 @@ if __name__ == "__main__":
     ap.add_argument("--blocks", type=int, default=3)
     ap.add_argument("--parity-loci", type=int, default=-1, help="-1: every locus; 0: none; n: n loci as a first, a middle and a last stretch")
     ap.add_argument("--slots", type=int, default=2, help="sets of output arrays + streams consecutive steps alternate between (1: one step at a time)")
-    ap.add_argument("--place", type=int, default=14, help="extra allocations of the read words tried at set-up, the fastest kept (0: none)")
+    ap.add_argument("--place", type=int, default=30, help="extra allocations of the read words tried at set-up, the fastest kept (0: none)")
     a = ap.parse_args()
     eng = Engine(0)
     cfg = synth.CONFIGS[a.config]
