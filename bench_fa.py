@@ -81,6 +81,7 @@ class AlignmentRun(object):
         self.host_plan = bool(os.environ.get("SMC_FA_HOST_PLAN"))      # (measurement: descriptors back to the host, smc_plan_create)
         self.t = {"build_issue": 0.0, "descriptors_d2h": 0.0, "plan_create": 0.0, "run_issue": 0.0, "n": 0}
         self.placement = None
+        self.active_slots = len(self.slots)            # (slots the steps alternate between: _place may leave it at one)
         if place > 0:
             self._place(place)
             self.words = self.slots[0]["words"]
@@ -121,7 +122,12 @@ class AlignmentRun(object):
         for sp in spacers:
             sp.free()
         eng.trim()                                  # (the candidates that lost go back to the runtime, not to the engine's spare list)
-        self.placement = {"walk_ms_by_allocation": [round(x, 3) for x in ms], "kept": [round(ms[i], 3) for i in order[:len(self.slots)]],
+        kept = [ms[i] for i in order[:len(self.slots)]]
+        # two slots buy ~ 1 % (the next step's builder beside this step's locus kernels) - less than a second-class allocation for
+        # the second slot costs: then every step goes through the first
+        if len(kept) > 1 and kept[1] > 1.015 * kept[0]:
+            self.active_slots = 1
+        self.placement = {"walk_ms_by_allocation": [round(x, 3) for x in ms], "kept": [round(x, 3) for x in kept], "slots_used": self.active_slots,
                           "note": "which allocation holds the read words moves the walk's time (DESIGN.md section 8); candidates are timed "
                                   "at set-up, outside every timed region, and the fastest kept"}
         for k in self.t:
@@ -142,8 +148,9 @@ class AlignmentRun(object):
         """build -> descriptors -> plan -> run; everything the product path does between the decoder and the rows."""
         eng, L = self.eng, self.eng.L
         if slot is None:
-            slot = self.k % len(self.slots)
+            slot = self.k
             self.k += 1
+        slot %= self.active_slots
         S = self.slots[slot]
         self.last_slot = slot
         st = S["stream"]
