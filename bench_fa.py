@@ -83,7 +83,11 @@ class AlignmentRun(object):
         self.placement = None
         self.active_slots = len(self.slots)            # (slots the steps alternate between: _place may leave it at one)
         if place > 0:
-            self._place(place)
+            try:
+                self._place(place)
+            except Exception as e:                       # (a failed trial allocation must not cost the run: take the arrays as they are)
+                self.placement = {"note": "placement trials abandoned: %s" % e}
+                eng.trim()
             self.words = self.slots[0]["words"]
 
     def _walk_ms(self, reps: int = 3) -> float:
@@ -108,8 +112,11 @@ class AlignmentRun(object):
             budget -= (mb << 20) + 4.0 * (self.ns + 64)
             if budget < 0:
                 break
-            spacers.append(DevBuf(eng, (mb << 20) + 4096))
-            cands.append(DevBuf(eng, 4 * (self.ns + 64)))
+            try:
+                spacers.append(DevBuf(eng, (mb << 20) + 4096))
+                cands.append(DevBuf(eng, 4 * (self.ns + 64)))
+            except Exception:                             # (memory is short: what has been allocated so far are the candidates)
+                break
         ms = []
         for w in cands:
             self.slots[0]["words"] = w
