@@ -107,6 +107,11 @@ class AlignmentRun(object):
         eng = self.eng
         cands, spacers = [S["words"] for S in self.slots], []
         budget = 110e9                                # bytes the candidates and their spacers may take together (of 288 GB)
+        try:
+            import torch
+            budget = min(budget, 0.6 * torch.cuda.mem_get_info(eng.device)[0])      # ... and of what is free now
+        except Exception:
+            pass
         for i in range(extra):
             mb = (37, 301, 1024, 2500, 150, 4097, 611, 1777)[i % 8]
             budget -= (mb << 20) + 4.0 * (self.ns + 64)
