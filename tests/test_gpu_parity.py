@@ -61,6 +61,28 @@ def test_synthetic_configs_vs_oracle(engine0, name, n):
     plan.close()
 
 
+def test_a_plan_run_again_and_again_with_every_locus_on_the_filter_worklist(engine0):
+    """k_filter_loci's last workgroup leaves the worklist empty for the plan's next run (no memset per run): a batch whose
+    every locus has a candidate, so that a count left standing would run the list past its end on the second run; the
+    host-made plan (zeroed before its first run) and the device-made one (zeroed by k_plan_classify)."""
+    import torch
+    cfg = synth.SynthConfig("allvar", 700, 40, 30, 20170501, alt_locus_frac=1.0, alt_af=0.3)
+    P = synth.params_for(cfg)
+    db = synth.generate_native(cfg, 0, cfg.n_loci, P)
+    want, fragile = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE, return_fragile=True)
+    assert int((want["cand"][:, 0]["flt_applied"] != 0).sum()) > 600
+    planes = engine0.upload(db)
+    d_loci = torch.from_numpy(np.ascontiguousarray(db.loci).view(np.uint8)).to("cuda:0")
+    for plan in (engine0.make_plan(db.loci), engine0.make_plan_dev(d_loci, cfg.n_loci)):
+        first = None
+        for _ in range(4):
+            got = plan.download(plan.run(planes, P))
+            assert abi.compare_rows(got, want, PI_TOL, P_TOL, fragile) == []
+            first = got.tobytes() if first is None else first
+            assert got.tobytes() == first
+        plan.close()
+
+
 def test_stress_mix_of_sizes_and_bins(engine0):
     """Loci of very different sizes in one batch: exercises every launch bin, including the
     global-scratch one, and the zero-coverage / tiny loci."""
