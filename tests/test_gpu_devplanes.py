@@ -384,6 +384,40 @@ def test_plan_made_on_the_device_gives_the_same_rows(engine0, tmp_path):
         assert r_host.tobytes() == r_dev.tobytes()
 
 
+def test_plans_made_in_a_row_on_two_streams(engine0):
+    """The statistics record smc_plan_create_dev sums into is the context's and is zeroed by the previous plan's k_plan_fill, not
+    by a memset: six plans of three different batches made back to back on two streams (a plan waits for the event behind the
+    previous plan's k_plan_fill), each run twice - the rows of the host-made plans, byte for byte."""
+    import torch
+    from smcounter_amd import devplanes, synth
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    batches = []
+    for name, n in (("C3", 700), ("C2", 2500), ("X6", 150)):
+        cfg = synth.CONFIGS[name]
+        P = synth.params_for(cfg)
+        db = synth.generate_native(cfg, 0, n, P)
+        planes = engine0.upload(db)
+        ph = engine0.make_plan(db.loci)
+        want = ph.download(ph.run(planes, P)).tobytes()
+        ph.close()
+        batches.append((db, P, planes, devplanes.DevLoci(engine0, db.loci), want))
+    torch.cuda.synchronize()
+    plans = []
+    for k in range(6):
+        db, P, planes, d_loci, want = batches[k % 3]
+        plans.append((engine0.make_plan_dev(d_loci, len(db.loci), stream=streams[k % 2]), k))
+    for plan, k in plans:
+        db, P, planes, d_loci, want = batches[k % 3]
+        for _ in range(2):
+            with torch.cuda.stream(streams[k % 2]):
+                got = plan.download(plan.run(planes, P, stream=streams[k % 2]))
+            assert got.tobytes() == want
+    for plan, _ in plans:
+        plan.close()
+    for b in batches:
+        b[3].free()
+
+
 def test_long_and_odd_cigars(engine0, tmp_path):
     """k_bp_lin makes the general CIGARs' copies operation by operation, 16 lanes per alignment: alignments with 5 ... 70 operations
     (more than 64: the exact path), a deletion straight after an insertion and the other way round, a reference skip next to an
