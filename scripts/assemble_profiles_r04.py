@@ -57,6 +57,26 @@ head = ('''# The step bench.py times (smc_build_planes -> smc_plan_create_dev ->
        100 * E["TCC_HIT_sum"] / (E["TCC_HIT_sum"] + E["TCC_MISS_sum"]), (E["TCC_HIT_sum"] + E["TCC_MISS_sum"]) / 1e6,
        int(NW), life / 1e3, 100 * act / life, 100 * wis / life, 100 * wany / life,
        E["SQ_INSTS_VALU"] / NW, E["SQ_INSTS_SALU"] / NW, E["SQ_INSTS_LDS"] / NW, E["SQ_INSTS_VMEM_RD"] / NW, E["SQ_INSTS_VMEM_WR"] / NW))
+# the locus kernel in the same passes (the step's second kernel; round 3's reading of it: profiles/r03_call_v2_counters.txt)
+Ck = [k for k in f if k.startswith("void k_call_v2<64>")]
+if Ck:
+    C = f[Ck[0]]
+    cw = C["SQ_WAVES"]
+    clife = 4 * C["SQ_WAVE_CYCLES"] / cw
+    cact, cwis, cwany = (4 * C[x] / cw for x in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"))
+    crd = 128 * C["TCC_EA0_RDREQ_128B_sum"] + 64 * C["TCC_EA0_RDREQ_64B_sum"] + 32 * C.get("TCC_EA0_RDREQ_32B_sum", 0)
+    cms = bench["step_breakdown"]["k_call_v2_ms"]
+    cneed = bench["consumer_only"]["roofline"]["needed_bytes_per_launch"]
+    head += ("""#
+# k_call_v2<64> (one wavefront per locus, 200,000 of them), per launch, same passes:
+#   a wavefront lives %.1f k cycles (round 3: 69.1 k): %.0f %% issuing, %.0f %% waiting for an issue slot, %.0f %% parked in s_waitcnt;
+#   %.0f VALU + %.0f SALU + %.0f LDS + %.0f vector loads per wavefront (round 3: 3411 + 1882 + 162 + 26)
+#   reads %.2f GB (%.2f M requests of 128 B) + writes %.2f GB against %.2f GB needed = %.2f x; in %.3f ms (HIP events of the bench run) = %.2f TB/s
+#   L2 %.0f %% of %.1f M requests hit
+""" % (clife / 1e3, 100 * cact / clife, 100 * cwis / clife, 100 * cwany / clife,
+       C["SQ_INSTS_VALU"] / cw, C["SQ_INSTS_SALU"] / cw, C["SQ_INSTS_LDS"] / cw, C["SQ_INSTS_VMEM_RD"] / cw,
+       crd / 1e9, C["TCC_EA0_RDREQ_128B_sum"] / 1e6, C["WRITE_SIZE"] * 1024 / 1e9, cneed / 1e9, (crd + C["WRITE_SIZE"] * 1024) / cneed, cms,
+       (crd + C["WRITE_SIZE"] * 1024) / cms / 1e9, 100 * C["TCC_HIT_sum"] / (C["TCC_HIT_sum"] + C["TCC_MISS_sum"]), (C["TCC_HIT_sum"] + C["TCC_MISS_sum"]) / 1e6))
 open(P + "/r04_from_alignments_pmc.txt", "w").write(
     head + "## kernels (traced run: %.3f ms per step, k_bp_emit2 %.3f ms by its HIP events)\n" % (fa_tr["ms_per_step"], fa_tr["roofline"]["kernel_ms"]) +
     open(O + "/fa_kernels.txt").read() + "## one step\n" + open(O + "/fa_timeline.txt").read() + "## counters\n" + open(O + "/fa_pmc_summary.txt").read())
