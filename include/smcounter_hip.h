@@ -306,7 +306,9 @@ int smc_plan_create(smc_ctx* ctx, const smc_locus* loci, int64_t n_loci, smc_pla
 void smc_plan_destroy(smc_plan* plan);
 /* The same plan for a batch whose descriptors are already on the DEVICE (smc_build_planes has just written them): the binning
  * runs there, only a small record (and the few loci deep enough to be cut into parts) comes back.  Enqueued on `stream`
- * behind whatever wrote `d_loci`; synchronises on it.  `d_loci` stays the caller's and must outlive the plan. */
+ * behind whatever wrote `d_loci`; synchronises on it.  `d_loci` stays the caller's and must outlive the plan.  Plans of one
+ * context may be made on different streams one after the other (the record they sum into is the context's: a plan's kernels wait
+ * for the plan before it to be through with it); a plan is run by one stream at a time. */
 int smc_plan_create_dev(smc_ctx* ctx, const smc_locus* d_loci, int64_t n_loci, void* stream, smc_plan** out);
 /* number of kernel launches one smc_plan_run issues, and bytes of device scratch it holds */
 int smc_plan_info(const smc_plan* plan, int32_t* n_launches, int64_t* scratch_bytes);
