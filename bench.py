@@ -296,7 +296,10 @@ def main():
     torch.cuda.synchronize()
     t_build = time.time() - t0
     rows = torch.empty(n_mine * abi.ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-    slot_streams = [run.stream_of(k) for k in range(a.slots)] if a.slots > 1 else None
+    # (buffer k of the pipeline is filled by step(slot=k), which runs on slot k % active_slots' stream - the placement trials may
+    # have left ONE active slot: the pipeline must order its waits and gathers against the stream that really fills the buffer,
+    # ADVICE r4)
+    slot_streams = [run.stream_of(k % run.active_slots) for k in range(a.slots)] if a.slots > 1 else None
 
     # N > 1: the rows of step i travel to rank 0 (RCCL, its own stream) while step i + 1 computes - two buffers per rank,
     # a buffer is reused only after its gather has completed (dist.RowPipeline).  What travels is the packed wire row
@@ -355,6 +358,22 @@ def main():
     _lib.check(L.smc_build_kernel_ms(eng.ctx, ctypes.byref(k_ms), ctypes.byref(k_n)), "smc_build_kernel_ms")
     L.smc_build_set_timing(eng.ctx, 0)
     elapsed = sorted(blocks)[len(blocks) // 2]                   # the median block
+    # what rank 0 received in the last step against what every rank sent (outside the timed region): a 64-bit sum over each
+    # rank's last buffer, compared with the sum over the block rank 0 holds for that rank
+    gather_check = None
+    if gather:
+        b_last = (pipe.n - 1) % len(pipe.bufs)
+        csum = lambda t: t.view(torch.int32).sum(dtype=torch.int64).reshape(1)
+        mine = csum(pipe.bufs[b_last])
+        mine = mine.cpu() if share_gpu else mine
+        sums = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(sums, mine)
+        if rank == 0:
+            got_sums = [int(csum(t).item()) for t in pipe.recv[b_last]]
+            sent = [int(t.item()) for t in sums]
+            gather_check = {"ranks": len(sent), "blocks_equal_what_was_sent": got_sums == sent, "bytes_per_rank": int(pipe.bufs[b_last].numel())}
+            if got_sums != sent:
+                raise SystemExit("bench.py: the rows rank 0 gathered differ from what the ranks sent: %r vs %r" % (got_sums, sent))
     # the locus kernels of the same planes, timed alone with one more plan (outside the timed region)
     if slot_streams is not None:
         torch.cuda.set_stream(torch.cuda.default_stream(dev))
@@ -408,11 +427,14 @@ def main():
                                "host_ms_per_step": {k: round(v / n_steps * 1e3, 3) for k, v in run.t.items() if k != "n"},
                                "pileup_reads_per_s": run.reads * a.steps / elapsed, "builder_status": status},
             "p_value_note": "C3 has no locus that reaches filterVariants (parity.loci_filtered 0): the p-value half of the metric is "
-                            "carried by other_configs X3 / EX / C5",
+                            "carried by from_alignments X3 / EX / C5 (the same step as the headline, variants under the reads) and by "
+                            "other_configs X3 / EX / C5 (read words resident)",
             "host_buffers": "inputs resident in HBM when the timed region starts; handing host buffers of planes instead "
                             "(smc_call_batch_host: H2D of 8 B/read + kernels + D2H of the rows) measured 1.94 M loci/s on C3 "
                             "(DESIGN.md section 5) - PCIe-bound, never `value`",
         }
+        if gather_check is not None:
+            out["gather_check"] = gather_check
         if cpu is not None:
             out["cpu_baseline"], out["cpu_baseline_c"] = cpu["python_pool"], cpu["c_port"]
             out["cpu_baseline_c_all_cores"] = cpu["c_port_all_cores"]
@@ -437,6 +459,19 @@ def main():
         out["other_configs"] = {}
         for name in ("C2", "C5", "X3", "EX"):           # X3: 30 % of the loci reach the filters; EX: the example run's statistics
             out["other_configs"][name] = other_config(eng, name, a, dev, nthreads, oracle)
+        # the same shapes through the WHOLE device path, as the headline goes: alignments (variants under the reads where the
+        # config has them: smc_synth_alignments' alt_locus_frac / alt_af) -> smc_build_planes -> smc_plan_create_dev ->
+        # smc_plan_run_words, every row against oracle/aln_planes.c + oracle/smc_oracle.c - BASELINE's configs[4] (C5), loci that
+        # reach filterVariants and its Fisher tests (X3, EX), the reference's own depth (EX) and the small batch (C2)
+        out["from_alignments"] = {}
+        for name in ("C5", "X3", "EX", "C2"):
+            torch.cuda.empty_cache()
+            eng.trim()
+            o = bench_fa.run_leg(eng, name, synth.CONFIGS[name].n_loci, a.steps, a.warmup, a.blocks, nthreads,
+                                 parity_loci=0 if a.no_parity else -1, slots=a.slots, place=0)
+            for k in ("placement", "generate_s"):
+                o.pop(k, None)
+            out["from_alignments"][name] = o
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:

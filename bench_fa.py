@@ -286,7 +286,8 @@ def roofline_block(run: AlignmentRun, k_ms: float, k_n: int, cfg_name: str):
 
 def run_leg(eng, cfg_name: str, n_loci: int, steps: int, warmup: int, blocks: int, nthreads: int, parity_loci: int = -1, slots: int = 2,
             place: int = 30):
-    """The leg on one GPU, alone (scripts, `python3 -m bench_fa`); bench.py drives the same pieces itself."""
+    """The leg on one GPU, alone (scripts, `python3 -m bench_fa`; bench.py's `from_alignments` entries of the shapes beside the
+    headline: C5, X3, EX, C2); bench.py drives the same pieces itself for the headline."""
     cfg = synth.CONFIGS[cfg_name]
     params = synth.params_for(cfg)
     L = eng.L
@@ -334,15 +335,20 @@ def run_leg(eng, cfg_name: str, n_loci: int, steps: int, warmup: int, blocks: in
         "slots": slots, "ms_per_step_one_at_a_time": serial, "placement": run.placement,
         "pileup_reads_per_s": run.reads * steps / el,
         "host_ms_per_step": {k: round(v / n * 1e3, 3) for k, v in run.t.items() if k != "n"},
-        "k_call_v2_ms": c_ms,
+        "k_bp_emit2_ms": k_ms.value, "k_call_v2_ms": c_ms,
         "roofline": roofline_block(run, k_ms.value, k_n.value, cfg_name),
+        # SURVEY.md 8d's per-locus figure (16 B per pileup read + 360 B per locus) charged to the WHOLE step
+        "whole_step_on_survey_8d": {"bytes_per_step": 16.0 * run.reads + 360.0 * run.nl,
+                                    "frac": (16.0 * run.reads + 360.0 * run.nl) / (el / steps) / 1e9 / HBM_PEAK_GBS},
         "builder_status": st,
         "generate_s": round(run.t_gen, 1),
     }
     if parity_loci:
         run.step(slot=0)
         L.smc_device_sync(eng.ctx)
-        out["parity"] = parity_full(run, nthreads, 0 if parity_loci < 0 else parity_loci)
+        # (the oracle's batch of a chunk is 16 B per pileup read on the host: chunks of ~ 60 M reads)
+        out["parity"] = parity_full(run, nthreads, 0 if parity_loci < 0 else parity_loci,
+                                    chunk=int(max(200, min(20000, 60e6 // max(1.0, run.reads / run.nl)))))
     run.close()
     return out
 

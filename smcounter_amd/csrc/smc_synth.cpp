@@ -44,6 +44,13 @@ struct Rng {   // xoshiro256** seeded by splitmix64
     uint32_t below(uint32_t n) { return (uint32_t)(((next() >> 32) * (uint64_t)n) >> 32); }
 };
 
+// uniform [0,1) from (key, a, b): the variant decisions of smc_synth_alignments
+static inline double hash_uni(uint64_t key, uint64_t a, uint64_t b) {
+    uint64_t x = key ^ (a * 0x9E3779B97F4A7C15ull) ^ (b * 0xC2B2AE3D27D4EB4Full);
+    x = Rng::sm(x);
+    return (x >> 11) * (1.0 / 9007199254740992.0);
+}
+
 struct Rd {
     uint32_t umi, frag;
     uint8_t allele, bq, mq, flags;   // flags: device flag byte
@@ -248,7 +255,7 @@ extern "C" {
 // rest single - all starting within 4 positions of the molecule's start, 100-150 bases long: depth ~ n_umi x rpb.  Reference
 // base at 1-based position p is "ACGT"[p % 4]; per-base sequencing error p_err; qualities / MAPQ / mismatch counts from the
 // distributions of the pileup generator above; 5 % of the alignments begin with a soft clip, p_ins_aln carry a one-base
-// insertion, p_del_aln a two-base deletion.  Alignments come out in coordinate order with run-wide barcode / fragment ids
+// insertion, p_del_aln a two-base deletion; alt_locus_frac / alt_af put variants under the reads (see the struct).  Alignments come out in coordinate order with run-wide barcode / fragment ids
 // numbered by first appearance, exactly as the decoder numbers them.  Deterministic for a given (seed, shape), whatever
 // the thread count.
 typedef struct smc_synth_acfg {
@@ -256,6 +263,12 @@ typedef struct smc_synth_acfg {
     int32_t n_umi, rpb;
     uint64_t seed;
     double p_overlap, p_err, p_ins_aln, p_del_aln, p_clip, mismatch_thr;
+    // variants (round 5; the pileup generator's alt_locus_frac / alt_af carried over to alignments): a fraction alt_locus_frac of
+    // the reference positions are variant sites; at such a site every MOLECULE (barcode) carries the transition (A<->G, C<->T)
+    // with probability alt_af - all its reads then show it there (sequencing errors on top), and each adds one to the read's
+    // mismatch count (the NM a mapper would report).  Both decisions are hashes of (seed, position[, molecule]): the same
+    // whatever the thread count or the run's extent.
+    double alt_locus_frac, alt_af;
 } smc_synth_acfg;
 typedef void (*smc_aln_alloc)(void* ctx, int64_t n_aln, int64_t n_cig, int64_t n_seq, int64_t n_loci, void** out);
 
@@ -368,6 +381,15 @@ int64_t smc_synth_alignments(const smc_synth_acfg* c, smc_aln_alloc alloc, void*
         }
     }
     if (slots >= (1ll << 32)) return -10;
+    // variant sites: one byte per 1-based reference position the run's reads can touch
+    const bool alt_on = c->alt_locus_frac > 0 && c->alt_af > 0;
+    const int64_t alt_base = p_lo - 16;                                    // (1-based position alt_base + k <-> altmap[k])
+    std::vector<uint8_t> altmap;
+    if (alt_on) {
+        altmap.resize((size_t)(span + 16 + 512));
+        for (size_t k = 0; k < altmap.size(); ++k)
+            altmap[k] = hash_uni(c->seed ^ 0x5A17E5ull, (uint64_t)(alt_base + (int64_t)k), 0) < c->alt_locus_frac;
+    }
     // records and pools, in parallel by alignment
     {
         static const char REF[5] = "ACGT";
@@ -386,8 +408,6 @@ int64_t smc_synth_alignments(const smc_synth_acfg* c, smc_aln_alloc alloc, void*
                     d.pos = a.pos; d.end = endp[(size_t)i];
                     d.cig_off = offc[(size_t)i]; d.seq_off = offs[(size_t)i];
                     d.n_cig = (uint16_t)(offc[(size_t)i + 1] - offc[(size_t)i]);
-                    const double mm100 = 100.0 * (double)a.mism / (double)a.len;                    // smCounter.py:352-356
-                    d.oflag = (uint8_t)((a.flag & 7) | (mm100 <= c->mismatch_thr ? SMC_DA_MMOK : 0));
                     d.mapq = a.mapq;
                     d.left_sp = (uint16_t)(a.kind == 1 ? a.clip : 0);
                     d.qalen = (uint16_t)(a.len - (a.kind == 1 ? a.clip : 0));
@@ -404,12 +424,24 @@ int64_t smc_synth_alignments(const smc_synth_acfg* c, smc_aln_alloc alloc, void*
                     uint8_t* ql = sq + 1;
                     for (size_t g = i ? (size_t)offs[(size_t)i - 1] + (size_t)al[(size_t)i - 1].len : 0; g < (size_t)offs[(size_t)i]; ++g) { ps[2 * g] = 'A'; ps[2 * g + 1] = 0; }   // (the gap before it)
                     int64_t rp = a.pos + 1;                              // 1-based reference position of the next match
+                    int n_alt = 0;                                       // variant sites at which this read's molecule carries the alt
                     for (int q = 0; q < a.len; ++q) {
                         bool off_ref = (a.kind == 1 && q < a.clip) || (a.kind == 2 && q == half);
                         if (a.kind == 3 && q == half) rp += 2;           // the two deleted bases
-                        sq[2 * q] = (uint8_t)(off_ref ? REF[g.below(4)] : REF[rp & 3]);
+                        uint8_t b = (uint8_t)(off_ref ? REF[g.below(4)] : REF[rp & 3]);
+                        if (alt_on && !off_ref) {
+                            const int64_t k = rp - alt_base;
+                            if (k >= 0 && k < (int64_t)altmap.size() && altmap[(size_t)k] &&
+                                hash_uni(c->seed ^ 0xA17A11E1Eull, (uint64_t)rp, (uint64_t)a.mol + 1) < c->alt_af) {
+                                b = (uint8_t)REF[(rp & 3) ^ 2];          // the transition: A<->G, C<->T
+                                ++n_alt;
+                            }
+                        }
+                        sq[2 * q] = b;
                         if (!off_ref) ++rp;
                     }
+                    const double mm100 = 100.0 * (double)(a.mism + n_alt) / (double)a.len;          // smCounter.py:352-356
+                    d.oflag = (uint8_t)((a.flag & 7) | (mm100 <= c->mismatch_thr ? SMC_DA_MMOK : 0));
                     // sequencing errors by geometric skipping
                     if (c->p_err > 0) {
                         const double lg = log1p(-c->p_err);

@@ -219,6 +219,12 @@ def build_run(A, L, eng, cp, params, chrom, lo, fasta, run_ref, planes, uaux, sl
     if (A["status"] & ~1) != 0 or deepest > max_depth or slot_base + ns > cap or \
             umi_base + ns + nl + 1 > cap + 8192:
         return None
+    if (A["status"] & 1) and len(A["aln"]):
+        # unflagged alignments: the walk looks back for the previous flagged pileup read of every such (read, locus) - fine for a
+        # sprinkle of them, quadratic for single-end data, and a run that BEGINS with one ends in the host builder's error anyway
+        unfl = (A["aln"]["oflag"] & 3) == 0
+        if bool(unfl[0]) or float(unfl.mean()) > 0.25:
+            return None
     up = lambda a: DevBuf(eng, a.nbytes + 256).upload(a.view(np.uint8).reshape(-1) if a.nbytes else np.zeros(4, np.uint8))
     d_aln, d_cig, d_bq, d_loc = up(A["aln"]), up(A["cig"]), up(A["bq"]), up(A["loc"])
     d_ref = up(np.frombuffer(run_ref[:nl].encode().ljust(nl, b"\0"), np.uint8).copy())

@@ -496,7 +496,8 @@ def aln_ref_fetch(start: int, end: int) -> str:
 
 def generate_alignments(cfg: SynthConfig, n_loci: int = None, params=None, nthreads: int = 0, host_array=None,
                         p_ins_aln: float = 0.02, p_del_aln: float = 0.02, p_clip: float = 0.05):
-    """A run of `n_loci` consecutive loci at cfg's depth shape (n_umi barcodes x rpb reads per locus) as the decoder would hand
+    """A run of `n_loci` consecutive loci at cfg's depth shape (n_umi barcodes x rpb reads per locus; cfg.alt_locus_frac of the
+    positions variant sites at which a molecule carries the transition with probability cfg.alt_af) as the decoder would hand
     it to smc_build_planes: dict(aln, cig, bq (+ its views seq, qual), loc, nl, n_slots, n_bc, n_pair, status, reads, start0).
     `host_array(name, dtype, count)` may provide the arrays (page-locked staging)."""
     import ctypes as C
@@ -507,7 +508,7 @@ def generate_alignments(cfg: SynthConfig, n_loci: int = None, params=None, nthre
     class ACfg(C.Structure):
         _fields_ = [("n_loci", C.c_int64), ("start0", C.c_int64), ("n_umi", C.c_int32), ("rpb", C.c_int32), ("seed", C.c_uint64),
                     ("p_overlap", C.c_double), ("p_err", C.c_double), ("p_ins_aln", C.c_double), ("p_del_aln", C.c_double),
-                    ("p_clip", C.c_double), ("mismatch_thr", C.c_double)]
+                    ("p_clip", C.c_double), ("mismatch_thr", C.c_double), ("alt_locus_frac", C.c_double), ("alt_af", C.c_double)]
 
     n_loci = cfg.n_loci if n_loci is None else n_loci
     params = params or params_for(cfg)
@@ -529,7 +530,7 @@ def generate_alignments(cfg: SynthConfig, n_loci: int = None, params=None, nthre
             out[k] = got[name].ctypes.data
     start0 = cfg.start_pos - 1                                     # the pileup generator's first locus, 0-based
     c = ACfg(n_loci, start0, cfg.n_umi, cfg.rpb, cfg.seed, cfg.p_overlap, cfg.p_err, p_ins_aln, p_del_aln, p_clip,
-             float(params.mismatchThr))
+             float(params.mismatchThr), cfg.alt_locus_frac, cfg.alt_af)
     n_slots, n_bc, n_pair = C.c_int64(0), C.c_int32(0), C.c_int32(0)
     nthreads = nthreads or min(32, len(os.sched_getaffinity(0)))
     n = lib.smc_synth_alignments(C.byref(c), alloc_t(alloc), None, C.byref(n_slots), C.byref(n_bc), C.byref(n_pair), nthreads)

@@ -1,0 +1,115 @@
+"""Loci WITH a variant through the whole device path: synthetic ALIGNMENTS with variants under the reads
+(smc_synth_alignments' alt_locus_frac / alt_af) -> smc_build_planes -> smc_plan_create_dev -> smc_plan_run_words, every row
+against the same alignments taken through oracle/aln_planes.c (the reference's per-pileup-read logic, smCounter.py:316-471) +
+oracle/smc_oracle.c (:26-98, :182-269, :482-600).  Integer columns and FILTER bits bit-exact, PI and Fisher p within 1e-6."""
+import os
+
+import numpy as np
+import pytest
+
+from smcounter_amd import abi, synth
+
+import oracle_lib
+
+pytestmark = pytest.mark.gpu
+PI_TOL = 1e-6
+P_TOL = 1e-6
+
+
+def _gpu_rows(engine0, A, P):
+    """The product path on one run of alignments: words built on the device, plan made on the device, rows back."""
+    from smcounter_amd import devplanes
+    rb = devplanes.resident_from_alignments(A, engine0, P, all_planes=False)
+    d_loci = devplanes.DevLoci(engine0, rb.loci)
+    plan = engine0.make_plan_dev(d_loci, rb.n_loci)
+    got = plan.run_devbuf([rb.words, rb.planes[4]], P).copy()
+    plan.close()
+    d_loci.free()
+    return rb, got
+
+
+def oracle_rows(A, P, chunk, cores):
+    """-> (rows, fragile, pi_all, alleles per locus) of every locus of the run, the oracle's way, chunk by chunk."""
+    want, fragile, pi_all, n_al = [], [], [], []
+    for c0 in range(0, A["nl"], chunk):
+        c1 = min(A["nl"], c0 + chunk)
+        db = oracle_lib.aln_planes(A, P, c0, c1, n_threads=cores)
+        w, f, p = oracle_lib.call_batch_mt(db, abi.c_params(P), abi.ROW_DTYPE, cores, return_fragile=True, return_pi_all=True)
+        want.append(w); fragile.append(f); pi_all.append(p); n_al.append(db.loci["n_alleles"].copy())
+    return np.concatenate(want), np.concatenate(fragile), np.concatenate(pi_all), np.concatenate(n_al)
+
+
+@pytest.mark.timeout(900)
+def test_x3_shaped_loci_from_alignments_reach_the_filters(engine0):
+    """24,000 loci of C3's depth shape with a 10 % variant at 30 % of the positions: a third of the rows goes through
+    filterVariants and its Fisher tests - from alignments, not from pre-built read words."""
+    cfg = synth.CONFIGS["X3"]
+    P = synth.params_for(cfg)
+    cores = len(os.sched_getaffinity(0))
+    A = synth.generate_alignments(cfg, 24000, P)
+    rb, got = _gpu_rows(engine0, A, P)
+    want, fragile, pi_all, n_al = oracle_rows(A, P, 8000, cores)
+    assert (rb.loci["n_alleles"] == n_al).all()
+    rep = abi.parity_report(got, want, fragile, pi_all, PI_TOL, P_TOL)
+    print("X3 from alignments:", {k: v for k, v in rep.items() if k != "detail"})
+    assert rep["loci"] == 24000 and rep["mismatches"] == 0, rep["detail"]
+    assert rep["loci_filtered"] >= 5000 and rep["fisher_tests_run"] >= 3 * rep["loci_filtered"]
+    assert rep["pi_max_abs_diff"] <= PI_TOL and rep["p_max_abs_diff"] <= P_TOL
+    assert rep["fragile_skipped"] + rep["near_tie_skipped"] <= 0.01 * rep["loci"]
+    # FILTER bits of every candidate the two agree on having
+    both = (got["cand"]["flt_applied"] != 0) & (want["cand"]["flt_applied"] != 0)
+    firm = np.ones(len(got), bool)
+    firm[list(abi.near_tie_loci(got, want, pi_all=pi_all))] = False
+    firm &= fragile == 0
+    assert (got["cand"]["flt"][both & firm[:, None]] == want["cand"]["flt"][both & firm[:, None]]).all()
+
+
+@pytest.mark.timeout(1500)
+def test_C5_from_alignments_every_row_and_cut_vcf(engine0, tmp_path):
+    """BASELINE configs[4] from ALIGNMENTS at its real size on one GPU: 100,000 loci at ~ 8000x (133 barcodes x 60 reads), a
+    0.5 % AF spike at 1 % of the positions.  Every row against the oracle, and the .cut.vcf written from the GPU rows equal to
+    the one written from the oracle's rows."""
+    from smcounter_amd import postfilter, rows, writers
+    cfg = synth.CONFIGS["C5"]
+    P = synth.params_for(cfg)
+    cores = len(os.sched_getaffinity(0))
+    A = synth.generate_alignments(cfg, cfg.n_loci, P)
+    rb, got = _gpu_rows(engine0, A, P)
+    want, fragile, pi_all, n_al = oracle_rows(A, P, 6000, cores)
+    assert (rb.loci["n_alleles"] == n_al).all()
+    rep = abi.parity_report(got, want, fragile, pi_all, PI_TOL, P_TOL)
+    print("C5 from alignments:", {k: v for k, v in rep.items() if k != "detail"})
+    assert rep["loci"] == cfg.n_loci and rep["mismatches"] == 0, rep["detail"]
+    assert rep["loci_filtered"] >= 100 and rep["fisher_tests_run"] > 0
+    assert rep["pi_max_abs_diff"] <= PI_TOL and rep["p_max_abs_diff"] <= P_TOL
+    firm = fragile == 0
+    firm[list(abi.near_tie_loci(got, want, pi_all=pi_all))] = False       # (order of two PI-tied alleles: unpinned)
+    ref = synth.CyclicRef()
+    thr = writers.pi_threshold(P.mtDepth, 0)
+    bodies = []
+    for tag, R in (("gpu", got), ("cpu", want)):
+        text = [t for t, f in zip(rows.format_rows(R, rb, P, ref), firm) if f]
+        prefix = str(tmp_path / tag)
+        writers.write_outputs(prefix, postfilter.apply_repeat_filters(text, {}, {}), thr)
+        bodies.append([l for l in open(prefix + ".smCounter.cut.vcf") if not l.startswith("#")])
+    assert bodies[0] == bodies[1]
+    print("C5 from alignments .cut.vcf: %d called variants, threshold %d" % (len(bodies[0]), thr))
+    assert len(bodies[0]) >= 5
+
+
+def test_example_depth_from_alignments(engine0):
+    """EX's statistics (the reference's own example run: ~ 58 k reads and ~ 4,900 barcodes per locus, a 10 % variant at 30 % of
+    the positions) from alignments: the deep class's parts and chunks behind the device builder, the Fisher tests on supports of
+    thousands."""
+    cfg = synth.CONFIGS["EX"]
+    P = synth.params_for(cfg)
+    cores = len(os.sched_getaffinity(0))
+    A = synth.generate_alignments(cfg, 400, P)
+    rb, got = _gpu_rows(engine0, A, P)
+    want, fragile, pi_all, n_al = oracle_rows(A, P, 200, cores)
+    assert (rb.loci["n_alleles"] == n_al).all() and int(rb.loci["n_reads"].min()) > 50000
+    rep = abi.parity_report(got, want, fragile, pi_all, PI_TOL, P_TOL)
+    print("EX from alignments:", {k: v for k, v in rep.items() if k != "detail"})
+    assert rep["mismatches"] == 0, rep["detail"]
+    assert rep["loci_filtered"] >= 80 and rep["fisher_tests_run"] >= 3 * rep["loci_filtered"]
+    assert rep["pi_max_abs_diff"] <= PI_TOL and rep["p_max_abs_diff"] <= P_TOL
