@@ -178,19 +178,18 @@ class Resident(object):
 
 def call_roofline(plan_loci, k_ms, k_n, k_loci, k_reads, cfg_key):
     """k_call_v2 alone: the bytes it HAS to move per launch (the read words - 4 B per read slot -, umi_start, descriptors, rows)
-    over its mean HIP-event duration, against the 8 TB/s peak.  SURVEY.md 8d's figure (16 B per read + 360 B per locus: the
-    four raw-field planes, which the plane builder digests into the one word per read the kernels load) is kept beside it; it
-    is not a fraction of anything this kernel does."""
+    over its mean HIP-event duration, against the 8 TB/s peak.  (SURVEY.md 8d's figure - 16 B per read + 360 B per locus - counts
+    the four raw-field planes the plane builder digests: it is charged to the WHOLE step, `whole_step_on_survey_8d`, not to a kernel
+    that moves a quarter of it.)"""
     import bench_fa
-    alg_bytes = 16.0 * k_reads + 360.0 * k_loci
     need = needed_bytes(plan_loci)
     achieved = need / (k_ms * 1e-3) / 1e9
-    rec = bench_fa.traffic_record(cfg_key)
+    rec, why = bench_fa.traffic_record(cfg_key)
     return {"kernel": "k_call_v2", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "frac_basis": "needed bytes per launch (4 B per read slot: the read word; + umi_start + descriptor + row) / kernel time / 8 TB/s",
             "traffic": rec["hbm_bytes_per_launch"] / (k_ms * 1e-3) / 1e9 if rec else None, "traffic_measured_in_run": False,
-            "kernel_ms": k_ms, "kernel_samples": k_n, "loci_per_launch": k_loci, "needed_bytes_per_launch": need,
-            "achieved_survey_8d": alg_bytes / (k_ms * 1e-3) / 1e9, "frac_survey_8d": alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            **({"traffic_note": why} if why else {}),
+            "kernel_ms": k_ms, "kernel_samples": k_n, "loci_per_launch": k_loci, "needed_bytes_per_launch": need}
 
 
 def physical_cores():
@@ -438,6 +437,7 @@ def main():
         if cpu is not None:
             out["cpu_baseline"], out["cpu_baseline_c"] = cpu["python_pool"], cpu["c_port"]
             out["cpu_baseline_c_all_cores"] = cpu["c_port_all_cores"]
+            out["cpu_baseline_c_from_alignments"] = cpu["c_from_alignments"]
             out["cpu_baseline_single_process"] = cpu["python_single"]
             out["cpu_baseline_pool_chunked"] = cpu["python_pool_chunked"]
         if world == 1 and not a.no_parity:
@@ -559,6 +559,15 @@ def cpu_leg(a):
     dt_cmt = (time.perf_counter() - t) / reps
     assert mt_rows.tobytes() == ref_rows.tobytes()
     phys = physical_cores()
+    # the C restatement FROM ALIGNMENTS - the work the timed GPU step does: oracle/aln_planes.c (pileup, allele,
+    # barcode / fragment bookkeeping, smCounter.py:316-471) + oracle/smc_oracle.c on every host core, alignments made before the clock
+    A = synth.generate_alignments(cfg, n, params, nthreads=min(48, cores))
+    t = time.perf_counter()
+    db_a = oracle_lib.aln_planes(A, params, 0, n, n_threads=cores)
+    dt_planes = time.perf_counter() - t
+    oracle_lib.call_batch_mt(db_a, abi.c_params(params), abi.ROW_DTYPE, cores)
+    dt_fa = time.perf_counter() - t
+    del A, db_a
     # one process, no pool: what one core does with the pure-Python restatement (no task pickling, no result pipes)
     n_one = min(n, 120)
     t = time.perf_counter()
@@ -599,6 +608,9 @@ def cpu_leg(a):
                                     % (n_one, dt_one)},
         "c_port": {"value": n / dt_c, "unit": "loci/s", "cores": 1, "kind": "port",
                    "sample": "first %d loci, C restatement oracle/smc_oracle.c, 1 thread, %.1f s" % (n, dt_c)},
+        "c_from_alignments": {"value": n / dt_fa, "unit": "loci/s", "cores": phys, "logical_cpus": cores, "kind": "port",
+                              "sample": "first %d loci AS ALIGNMENTS (what the timed GPU step starts from): oracle/aln_planes.c %.2f s + "
+                                        "oracle/smc_oracle.c %.2f s on %d threads" % (n, dt_planes, dt_fa - dt_planes, cores)},
         "c_port_all_cores": {"value": n / dt_cmt, "unit": "loci/s", "cores": phys, "logical_cpus": cores, "kind": "port",
                              "sample": "first %d loci, C restatement oracle/smc_oracle.c on %d threads (contiguous locus "
                                        "ranges), mean of %d passes, %.3f s each" % (n, cores, reps, dt_cmt)}}

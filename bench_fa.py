@@ -261,16 +261,33 @@ def parity_full(run: AlignmentRun, nthreads: int, n_loci: int = 0, chunk: int = 
     return tot
 
 
+def lib_sha16() -> str:
+    """First 16 hex digits of sha256(libsmcounter_hip.so): what a traffic record was measured on."""
+    import hashlib
+    from smcounter_amd import build
+    with open(os.environ.get("SMC_HIP_LIB") or build.LIB, "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()[:16]
+
+
 def traffic_record(key: str):
+    """-> (record of profiles/traffic.json or None, why not).  A record carries the hash of the library its counters were taken
+    on (`lib_sha16`): when the library that runs now is another one, the PMC bytes say nothing about it and are not printed."""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        return json.load(open(tpath)).get(key)
-    return None
+    if not os.path.exists(tpath):
+        return None, "no profiles/traffic.json"
+    rec = json.load(open(tpath)).get(key)
+    if rec is None:
+        return None, "no PMC record for %s in profiles/traffic.json" % key
+    have = lib_sha16()
+    if rec.get("lib_sha16") != have:
+        return None, ("profiles/traffic.json's record for %s was measured on library %s, this run's is %s: not printed"
+                      % (key, rec.get("lib_sha16", "(unrecorded)"), have))
+    return rec, None
 
 
 def roofline_block(run: AlignmentRun, k_ms: float, k_n: int, cfg_name: str):
     need = run.needed_bytes()
-    rec = traffic_record("fa:%s:%d" % (cfg_name, run.nl))
+    rec, why = traffic_record("fa:%s:%d" % (cfg_name, run.nl))
     traffic = rec["hbm_bytes_per_launch"] / (k_ms * 1e-3) / 1e9 if rec else None
     return {"bound": "hbm", "kernel": "k_bp_emit2 (the walk that writes the read words: the step's dominant kernel)",
             "kernel_ms": k_ms, "kernel_samples": k_n, "needed_bytes_per_launch": need,
@@ -279,7 +296,7 @@ def roofline_block(run: AlignmentRun, k_ms: float, k_n: int, cfg_name: str):
             "frac_basis": "needed bytes: 2 B in (base + quality) + 4 B out (the read word) per pileup read, alignment + row records "
                           "and CIGARs once, umi_start + descriptor per locus; over the kernel's mean HIP-event duration",
             "reads_per_s_kernel": run.reads / (k_ms * 1e-3),
-            "traffic": traffic, "traffic_measured_in_run": False,
+            "traffic": traffic, "traffic_measured_in_run": False, **({"traffic_note": why} if why else {}),
             "traffic_source": ("profiles/traffic.json <- " + rec.get("source", "rocprofv3 --pmc")) if rec else None,
             "hbm_bytes_per_launch_pmc": rec["hbm_bytes_per_launch"] if rec else None}
 

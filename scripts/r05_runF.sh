@@ -1,0 +1,14 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05f; mkdir -p $O
+cd $R
+timeout 900 python -m pytest tests/test_gpu_devplanes.py tests/test_gpu_from_alignments.py tests/test_bam_golden.py -m gpu -x -q > $O/pytest.txt 2>&1
+tail -4 $O/pytest.txt
+for c in EX C5; do
+  timeout 300 python3 -m bench_fa --config $c --steps 10 --warmup 3 --blocks 3 --parity-loci 0 --place 0 --slots 1 > $O/fa_$c.json 2>/dev/null
+  python3 -c "
+import json,sys
+d=json.load(open('$O/fa_$c.json'))
+print('$c', round(d['value']/1e6,3), 'M loci/s', round(d['ms_per_step'],3), 'ms; emit2', round(d['k_bp_emit2_ms'],3), 'call', round(d['k_call_v2_ms'],3))"
+done
+SMC_VMM_CHUNK_MB=0 timeout 400 python3 scripts/ab_build.py 200000 libv_base.so libv_aux1.so libv_aux2.so libv_aux3.so libv_aux16.so libv_aux17.so libv_aux18.so libv_base.so > $O/ab_aux.txt 2>&1
+cat $O/ab_aux.txt

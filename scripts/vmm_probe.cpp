@@ -48,3 +48,43 @@ int plain_free(void* p) { return hipFree(p) == hipSuccess ? 0 : 1; }
 int mem_info(size_t* fr, size_t* tot) { return hipMemGetInfo(fr, tot) == hipSuccess ? 0 : 1; }
 
 }  // extern "C"
+
+// ---- does it matter WHICH XCD writes WHICH part of an allocation?  Workgroups are dealt to the eight XCDs round-robin by index:
+// only those of one XCD stream-write one region; host times every (region, XCD) pair with events.
+__global__ __launch_bounds__(256) void k_region_write(uint4* __restrict__ p, size_t n16, int xcd, uint32_t val) {
+    if ((int)(blockIdx.x & 7u) != xcd && xcd >= 0) return;
+    const size_t nb = xcd >= 0 ? gridDim.x / 8 : gridDim.x, b = xcd >= 0 ? blockIdx.x / 8 : blockIdx.x;
+    for (size_t i = b * 256 + threadIdx.x; i < n16; i += nb * 256) p[i] = make_uint4(val, val, val, val);
+}
+__global__ __launch_bounds__(256) void k_region_read(const uint4* __restrict__ p, size_t n16, int xcd, uint32_t* sink) {
+    if ((int)(blockIdx.x & 7u) != xcd && xcd >= 0) return;
+    const size_t nb = xcd >= 0 ? gridDim.x / 8 : gridDim.x, b = xcd >= 0 ? blockIdx.x / 8 : blockIdx.x;
+    uint32_t acc = 0;
+    for (size_t i = b * 256 + threadIdx.x; i < n16; i += nb * 256) { const uint4 v = p[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
+    if (acc == 0x12345u) *sink = acc;
+}
+extern "C" int region_matrix(void* base, size_t bytes, size_t region, int write, float* out_ms /* [n_regions][9]: XCD 0-7, then all */) {
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 1;
+    uint32_t* sink = nullptr;
+    if (hipMalloc(&sink, 4) != hipSuccess) return 2;
+    const size_t nr = bytes / region;
+    for (size_t r = 0; r < nr; ++r)
+        for (int x = 0; x < 9; ++x) {
+            uint4* p = (uint4*)((char*)base + r * region);
+            const int xcd = x < 8 ? x : -1;
+            float best = 1e9f;
+            for (int rep = 0; rep < 3; ++rep) {
+                hipEventRecord(e0, 0);
+                if (write) hipLaunchKernelGGL(k_region_write, dim3(2048), dim3(256), 0, 0, p, region / 16, xcd, (uint32_t)rep);
+                else hipLaunchKernelGGL(k_region_read, dim3(2048), dim3(256), 0, 0, (const uint4*)p, region / 16, xcd, sink);
+                hipEventRecord(e1, 0);
+                hipEventSynchronize(e1);
+                float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+                if (rep && ms < best) best = ms;
+            }
+            out_ms[r * 9 + x] = best;
+        }
+    hipFree(sink); hipEventDestroy(e0); hipEventDestroy(e1);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}

@@ -41,6 +41,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
