@@ -50,9 +50,11 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps each; value = the median block")
-    ap.add_argument("--place", type=int, default=30,
-                    help="extra allocations of the read words tried at set-up, the fastest kept: which allocation holds the array moves "
-                         "the walk's time by up to 10 %% (DESIGN.md section 8); 0: take what comes")
+    ap.add_argument("--place", type=int, default=0,
+                    help="(round 4's bench-side trials, kept for comparison) extra allocations of the read words tried by the BENCH at "
+                         "set-up, each timed with the real walk, the fastest kept.  Default 0: the library places the array itself - "
+                         "engine.DevBuf(walk_output=True) -> smc_mem_alloc_best, a write-pattern probe over up to SMC_ALLOC_TRIES "
+                         "(12) allocations, as every caller of the product path gets it (DESIGN.md section 5)")
     ap.add_argument("--slots", type=int, default=2,
                     help="sets of output arrays (each with a stream of its own) consecutive steps alternate between: with 2 the builder "
                          "of step i + 1 is enqueued while the locus kernels of step i run; 1: one step at a time")
@@ -422,6 +424,9 @@ def main():
                     "achieved": (16.0 * run.reads + 360.0 * run.nl) / (elapsed / a.steps) / 1e9, "unit": "GB/s",
                     "frac": (16.0 * run.reads + 360.0 * run.nl) / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS}}),
             "step_breakdown": {"slots": a.slots, "ms_per_step_one_at_a_time": serial_ms, "placement": run.placement,
+                               # what the library's write-pattern probe saw when it chose the blocks of the read words (one per slot)
+                               "allocation": {"chosen_by": "smc_mem_alloc_best (engine.DevBuf(walk_output=True))", "tries": eng.alloc_tries,
+                                              "blocks": list(eng.alloc_log)},
                                "k_bp_emit2_ms": k_ms.value, "k_call_v2_ms": c_ms,
                                "host_ms_per_step": {k: round(v / n_steps * 1e3, 3) for k, v in run.t.items() if k != "n"},
                                "pileup_reads_per_s": run.reads * a.steps / elapsed, "builder_status": status},

@@ -33,7 +33,8 @@ class AlignmentRun(object):
     its molecules are drawn from another seed) - the weak-scaling input of rank `shard`."""
 
     def __init__(self, eng, cfg, params, n_loci, nthreads, shard: int = 0, slots: int = 1, place: int = 0):
-        """`slots` > 1: consecutive steps alternate between that many sets of output arrays, each with a stream of its own - the
+        """(The read words of every slot are a block the LIBRARY chose: engine.DevBuf(walk_output=True) -> smc_mem_alloc_best.)
+        `slots` > 1: consecutive steps alternate between that many sets of output arrays, each with a stream of its own - the
         builder of step i + 1 is then enqueued while the locus kernels of step i still run (the host waits, inside
         smc_plan_create_dev, only for the builder of the step it is issuing), as the runs of a BAM follow each other.
         `place` > 0: WHICH ALLOCATION holds the read words moves the walk's time by up to 10 % (1.33 / 1.38 / 1.46 ms
@@ -61,7 +62,7 @@ class AlignmentRun(object):
         self.xcap = 4 * self.nl + 4096
         self.slots = []
         for k in range(max(1, slots)):
-            S = {"words": DevBuf(eng, 4 * (self.ns + 64)), "uaux": [DevBuf(eng, 4 * (self.ns + self.nl + 64)) for _ in range(3)],
+            S = {"words": DevBuf(eng, 4 * (self.ns + 64), walk_output=True), "uaux": [DevBuf(eng, 4 * (self.ns + self.nl + 64)) for _ in range(3)],
                  "d_loci": DevBuf(eng, self.nl * LOCUS_DTYPE.itemsize), "d_x": DevBuf(eng, 20 * self.xcap), "d_cnt": DevBuf(eng, 8),
                  "rows": DevBuf(eng, self.nl * abi.ROW_DTYPE.itemsize), "stream": None}
             if slots > 1:
@@ -302,7 +303,7 @@ def roofline_block(run: AlignmentRun, k_ms: float, k_n: int, cfg_name: str):
 
 
 def run_leg(eng, cfg_name: str, n_loci: int, steps: int, warmup: int, blocks: int, nthreads: int, parity_loci: int = -1, slots: int = 2,
-            place: int = 30):
+            place: int = 0):
     """The leg on one GPU, alone (scripts, `python3 -m bench_fa`; bench.py's `from_alignments` entries of the shapes beside the
     headline: C5, X3, EX, C2); bench.py drives the same pieces itself for the headline."""
     cfg = synth.CONFIGS[cfg_name]
@@ -387,7 +388,7 @@ if __name__ == "__main__":
     ap.add_argument("--blocks", type=int, default=3)
     ap.add_argument("--parity-loci", type=int, default=-1, help="-1: every locus; 0: none; n: n loci as a first, a middle and a last stretch")
     ap.add_argument("--slots", type=int, default=2, help="sets of output arrays + streams consecutive steps alternate between (1: one step at a time)")
-    ap.add_argument("--place", type=int, default=30, help="extra allocations of the read words tried at set-up, the fastest kept (0: none)")
+    ap.add_argument("--place", type=int, default=0, help="bench-side trials: extra allocations of the read words timed with the real walk at set-up, the fastest kept (0: the library's own placement only)")
     a = ap.parse_args()
     eng = Engine(0)
     cfg = synth.CONFIGS[a.config]

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SMC_ABI_VERSION 5
+#define SMC_ABI_VERSION 6
 #define SMC_MAX_ALLELES 64 /* allele ids per locus; ids 0-5 are A,T,G,C,N,'DEL' */
 
 /* error codes */
@@ -399,6 +399,14 @@ int smc_pool_trim(smc_ctx* ctx);
  * Pointers from it are freed with smc_mem_free only. */
 int smc_mem_alloc(smc_ctx* ctx, int64_t bytes, void** out);
 void smc_mem_free(smc_ctx* ctx, void* p);
+/* For an array the plane builder's walk WRITES (the read words of a batch): which physical pages hold it moves that kernel by up to
+ * 10 % (the same from launch to launch; no counter of translation, L2 or request counts tells a fast allocation from a slow one,
+ * but a write-only kernel with the walk's pattern does: smc_mem_write_probe).  smc_mem_alloc_best makes up to `tries` allocations
+ * (virtual-memory ranges over handles of different sizes and plain blocks), times that pattern into each (~ 4 ms per candidate)
+ * and keeps the fastest.  info (may be NULL): [0] the kept block's probe time in ms, [1] the slowest candidate's, [2] candidates
+ * tried.  Freed with smc_mem_free. */
+int smc_mem_alloc_best(smc_ctx* ctx, int64_t bytes, int tries, void** out, float* info);
+int smc_mem_write_probe(smc_ctx* ctx, void* p, int64_t bytes, float* ms);
 /* page-locked host memory: copies to and from it run at the link's rate (pageable memory goes through a staging copy) */
 int smc_mem_alloc_host(smc_ctx* ctx, int64_t bytes, void** out);
 void smc_mem_free_host(smc_ctx* ctx, void* p);

@@ -88,3 +88,30 @@ extern "C" int region_matrix(void* base, size_t bytes, size_t region, int write,
     hipFree(sink); hipEventDestroy(e0); hipEventDestroy(e1);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
+
+// the same range, its physical handles created in order and MAPPED IN A SHUFFLED ORDER: virtual neighbours are then physical strangers
+extern "C" int vmm_alloc_shuffled(int device, size_t bytes, size_t chunk, uint64_t seed, void** out) {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess) return 1;
+    chunk = (chunk + gran - 1) / gran * gran;
+    const size_t n = (bytes + chunk - 1) / chunk, total = n * chunk;
+    void* va = nullptr;
+    if (hipMemAddressReserve(&va, total, (size_t)2 << 20, nullptr, 0) != hipSuccess) return 2;
+    std::vector<hipMemGenericAllocationHandle_t> h(n);
+    for (size_t i = 0; i < n; ++i) if (hipMemCreate(&h[i], chunk, &prop, 0) != hipSuccess) return 3;
+    std::vector<size_t> perm(n);
+    for (size_t i = 0; i < n; ++i) perm[i] = i;
+    uint64_t x = seed * 0x9E3779B97F4A7C15ull + 1;
+    for (size_t i = n - 1; i > 0; --i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; std::swap(perm[i], perm[(size_t)(x % (i + 1))]); }
+    for (size_t i = 0; i < n; ++i) {
+        if (hipMemMap((char*)va + i * chunk, chunk, 0, h[perm[i]], 0) != hipSuccess) return 4;
+        (void)hipMemRelease(h[perm[i]]);
+    }
+    hipMemAccessDesc ad = {};
+    ad.location.type = hipMemLocationTypeDevice; ad.location.id = device; ad.flags = hipMemAccessFlagsProtReadWrite;
+    if (hipMemSetAccess(va, total, &ad, 1) != hipSuccess) return 5;
+    *out = va;
+    return 0;
+}

@@ -14,7 +14,7 @@ SYMBOLS = ("smc_abi_version", "smc_last_error", "smc_row_size", "smc_locus_size"
            "smc_create", "smc_destroy", "smc_plan_create", "smc_plan_create_dev", "smc_plan_destroy", "smc_plan_info",
            "smc_plan_run", "smc_plan_run_words", "smc_pack_words", "smc_plan_set_timing", "smc_plan_kernel_ms", "smc_call_batch_host", "smc_event_create", "smc_event_record",
            "smc_event_elapsed_ms", "smc_event_destroy", "smc_class_table", "smc_wire_row_size", "smc_pack_rows", "smc_unpack_rows",
-           "smc_build_planes", "smc_build_max_depth", "smc_build_set_timing", "smc_build_kernel_ms", "smc_mem_alloc", "smc_mem_free", "smc_mem_h2d", "smc_mem_d2h",
+           "smc_build_planes", "smc_build_max_depth", "smc_build_set_timing", "smc_build_kernel_ms", "smc_mem_alloc", "smc_mem_alloc_best", "smc_mem_write_probe", "smc_mem_free", "smc_mem_h2d", "smc_mem_d2h",
            "smc_mem_alloc_host", "smc_mem_free_host", "smc_pool_trim",
            "smc_device_sync")
 
@@ -74,6 +74,8 @@ def load(with_torch: bool = True):
     L.smc_pack_rows.argtypes = [vp, vp, i64, vp, vp]
     L.smc_unpack_rows.argtypes = [vp, i64, vp]
     L.smc_mem_alloc.argtypes = [vp, i64, ctypes.POINTER(vp)]
+    L.smc_mem_alloc_best.argtypes = [vp, i64, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_float)]
+    L.smc_mem_write_probe.argtypes = [vp, vp, i64, ctypes.POINTER(ctypes.c_float)]
     L.smc_mem_free.argtypes = [vp, vp]
     L.smc_mem_free.restype = None
     L.smc_mem_alloc_host.argtypes = [vp, i64, ctypes.POINTER(vp)]
@@ -93,7 +95,7 @@ def load(with_torch: bool = True):
     L.smc_event_elapsed_ms.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_float)]
     L.smc_event_destroy.argtypes = [vp]
     L.smc_event_destroy.restype = None
-    if L.smc_abi_version() != 5:
+    if L.smc_abi_version() != 6:
         raise SmcError("ABI version mismatch")
     if L.smc_row_size() != abi.ROW_DTYPE.itemsize or L.smc_locus_size() != 32 or L.smc_wire_row_size() != abi.WIRE_DTYPE.itemsize:
         raise SmcError("struct layout mismatch between include/smcounter_hip.h and smcounter_amd/abi.py")

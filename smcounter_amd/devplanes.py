@@ -120,7 +120,7 @@ def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], par
     while i < n:
         first = i
         planes = [DevBuf(eng, 4 * cap) if all_planes else None for k in range(4)]
-        words = DevBuf(eng, 4 * cap)
+        words = DevBuf(eng, 4 * cap, walk_output=True)                # (a large one is chosen by the write-pattern probe: engine.DevBuf)
         uaux = [DevBuf(eng, 4 * (cap + 8192)) for _ in range(3)]      # umi_start, u_gid, u_finc
         LC, chroms, poss, refs, tables = [], [], [], [], []
         total = slots = n_loc = 0
@@ -318,7 +318,7 @@ def resident_from_alignments(A, eng, params, all_planes: bool = True, chrom: str
     nl, ns, lo = A["nl"], A["n_slots"], int(A["start0"])
     cap = ns + 64
     planes = [DevBuf(eng, 4 * cap) if all_planes else None for k in range(4)]
-    words = DevBuf(eng, 4 * cap)
+    words = DevBuf(eng, 4 * cap, walk_output=True)
     uaux = [DevBuf(eng, 4 * (cap + nl + 8192)) for _ in range(3)]
     run_ref = synth.aln_ref_fetch(lo, lo + nl)
     ref = synth.CyclicRef()

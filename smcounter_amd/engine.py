@@ -19,17 +19,28 @@ class DevBuf(object):
     """A device allocation owned through the C ABI (smc_mem_*): what the command line uses instead of a torch tensor, so
     that a single-process run never imports PyTorch.  Quacks like one where the bindings need it (`data_ptr()`)."""
 
-    def __init__(self, eng, nbytes: int):
+    def __init__(self, eng, nbytes: int, walk_output: bool = False):
+        """`walk_output`: the array is one the plane builder's walk writes (the read words of a batch).  Which physical pages hold
+        it moves that kernel by up to 10 %, so a block of 256 MB or more is chosen among `eng.alloc_tries`
+        allocations by the library's write-pattern probe (smc_mem_alloc_best, a few milliseconds per candidate, once: the block
+        then serves every later batch of the process through the engine's spare list)."""
         # Sizes are rounded up to {1, 1.25, 1.5, 1.75} x 2^k and a freed allocation waits in the engine for the next request
         # of its size class (a batch allocates and frees some twenty buffers; the runtime's free synchronises the device)
         self.eng, self.nbytes = eng, int(nbytes)
         self.cls = _size_class(self.nbytes)
-        spare = eng._spare.get(self.cls)
+        self.tuned = bool(walk_output) and eng.alloc_tries > 1 and self.cls >= TUNED_MIN_BYTES
+        spare = (eng._spare_tuned if self.tuned else eng._spare).get(self.cls)
         if spare:
             self.ptr = spare.pop()
             return
         p = ctypes.c_void_p()
-        _lib.check(eng.L.smc_mem_alloc(eng.ctx, self.cls, ctypes.byref(p)), "smc_mem_alloc")
+        if self.tuned:
+            info = (ctypes.c_float * 3)()
+            _lib.check(eng.L.smc_mem_alloc_best(eng.ctx, self.cls, eng.alloc_tries, ctypes.byref(p), info), "smc_mem_alloc_best")
+            eng.alloc_log.append({"bytes": self.cls, "probe_ms_kept": round(float(info[0]), 3), "probe_ms_slowest": round(float(info[1]), 3),
+                                  "candidates": int(info[2])})
+        else:
+            _lib.check(eng.L.smc_mem_alloc(eng.ctx, self.cls, ctypes.byref(p)), "smc_mem_alloc")
         self.ptr = p.value or 0
 
     def data_ptr(self) -> int:
@@ -55,7 +66,7 @@ class DevBuf(object):
 
     def free(self):
         if self.ptr and self.eng.ctx:
-            self.eng._spare.setdefault(self.cls, []).append(self.ptr)
+            (self.eng._spare_tuned if self.tuned else self.eng._spare).setdefault(self.cls, []).append(self.ptr)
         self.ptr = 0
 
     def __del__(self):
@@ -63,6 +74,9 @@ class DevBuf(object):
             self.free()
         except Exception:
             pass
+
+
+TUNED_MIN_BYTES = 256 << 20      # (smc_mem_alloc_best's own threshold)
 
 
 def _size_class(n: int) -> int:
@@ -90,6 +104,12 @@ class Engine(object):
         _lib.check(self.L.smc_create(device, ctypes.byref(h)), "smc_create")
         self.ctx = h
         self._spare = {}                      # size class -> freed DevBuf pointers, reused before allocating anew
+        self._spare_tuned = {}                # ... of the blocks chosen by the write-pattern probe (DevBuf(walk_output=True))
+        import os
+        # candidates per such block (1: take what comes).  About one allocation in eight is of the fast kind; the search stops at
+        # the first it finds, a candidate costs ~ 5 ms of probing + its allocation (1-80 ms for 2.4 GB)
+        self.alloc_tries = int(os.environ.get("SMC_ALLOC_TRIES", "12"))
+        self.alloc_log = []                   # what the probe saw, per chosen block
         self._pinned = {}                     # name -> (pointer, bytes) of page-locked staging memory
         self.last_rows = None                 # rows of the last vc.vc_resident call (pinned staging: valid until the next)
 
@@ -113,10 +133,11 @@ class Engine(object):
         """Give the cached device buffers (DevBuf) and the context's pool of plan blocks back to the runtime."""
         if self.ctx:
             self.L.smc_pool_trim(self.ctx)
-            for ptrs in self._spare.values():
+            for ptrs in list(self._spare.values()) + list(self._spare_tuned.values()):
                 for p in ptrs:
                     self.L.smc_mem_free(self.ctx, p)
         self._spare = {}
+        self._spare_tuned = {}
 
     def close(self):
         if self.ctx:

@@ -113,3 +113,33 @@ def test_example_depth_from_alignments(engine0):
     assert rep["mismatches"] == 0, rep["detail"]
     assert rep["loci_filtered"] >= 80 and rep["fisher_tests_run"] >= 3 * rep["loci_filtered"]
     assert rep["pi_max_abs_diff"] <= PI_TOL and rep["p_max_abs_diff"] <= P_TOL
+
+
+def test_large_blocks_virtual_memory_backing_and_the_write_pattern_probe(engine0):
+    """smc_mem_alloc backs blocks of 256 MB and more by HIP virtual memory over 64 MB handles, smc_mem_alloc_best picks one of
+    several candidates by the walk's write pattern: both must behave like any device block - copies in and out, kernels reading
+    and writing across the handle boundaries, freeing."""
+    import ctypes
+    from smcounter_amd import _lib
+    from smcounter_amd.engine import DevBuf
+    L = engine0.L
+    n = (300 << 20) // 4
+    rng = np.random.default_rng(5)
+    src = rng.integers(0, 1 << 32, size=n, dtype=np.uint32)
+    plain = DevBuf(engine0, 4 * n)
+    tuned = DevBuf(engine0, 4 * n, walk_output=True)
+    assert tuned.tuned and engine0.alloc_log and engine0.alloc_log[-1]["candidates"] >= 1
+    for b in (plain, tuned):
+        b.upload(src)
+        assert (b.download(np.uint32, n) == src).all()
+        b.upload(src[::-1].copy(), 0)
+        assert (b.download(np.uint32, 1 << 20, 4 * (n - (1 << 20))) == src[::-1][n - (1 << 20):]).all()
+    ms = ctypes.c_float()
+    _lib.check(L.smc_mem_write_probe(engine0.ctx, ctypes.c_void_p(tuned.data_ptr()), 4 * n, ctypes.byref(ms)), "smc_mem_write_probe")
+    assert 0.0 < ms.value < 1000.0
+    plain.free(); tuned.free()
+    engine0.trim()
+    again = DevBuf(engine0, 4 * n, walk_output=True)              # (after the trim: a fresh choice)
+    again.upload(src)
+    assert (again.download(np.uint32, n) == src).all()
+    again.free()
