@@ -25,8 +25,12 @@ Prints ONE JSON line on rank 0: value = loci of all ranks / max-over-ranks time;
 CPU legs timed on a bounded sample of the same workload (rank 0, N = 1 only; inputs made before the clock starts); parity = EVERY
 row of the run against the CPU (oracle/aln_planes.c + oracle/smc_oracle.c from the same alignments), with the number of loci
 whose order-dependent fields were excused, the loci that reached filterVariants, the Fisher tests run and the largest p-value
-difference; consumer_only = the locus kernels alone over resident read words (C3) and other_configs = the other single-GPU shapes
-that way (C2, C5, X3 - 30 % of the loci with a candidate -, EX - the statistics of the reference's own example run).
+difference; from_alignments = the SAME step on the other single-GPU shapes, variants under the reads where the config has them
+(C5 = BASELINE's configs[4], X3 - 30 % of the loci with a candidate -, EX - the statistics of the reference's own example run -, C2),
+every row checked the same way: where the p-value half of the metric is exercised; consumer_only = the locus kernels alone over
+resident read words (C3) and other_configs = the other shapes that way.
+The read words of a run live in a block the LIBRARY chose (engine.DevBuf(walk_output=True) -> smc_mem_alloc_best: step_breakdown
+.allocation says what its probe saw); --place N > 0 adds round 4's bench-side trials for comparison.
 """
 from __future__ import annotations
 

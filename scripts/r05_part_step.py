@@ -11,10 +11,10 @@ L = eng.L
 cfg = synth.CONFIGS["C3"]
 run = bench_fa.AlignmentRun(eng, cfg, synth.params_for(cfg), 200000, 48, slots=1, place=0)
 cands = [run.slots[0]["words"]] + [DevBuf(eng, 4 * (run.ns + 64)) for _ in range(3)]
-print("%-14s %s" % ("allocation", "".join("%22s" % ("part %d: walk / step" % p) for p in (64, 128, 192, 256))))
+print("%-14s %s" % ("allocation", "".join("%22s" % ("part %d: walk / step" % p) for p in (128, 256, 512, 1024))))
 for k, c in enumerate(cands):
     row = []
-    for p in (64, 128, 192, 256):
+    for p in (128, 256, 512, 1024):
         os.environ["SMC_BP_PART"] = str(p)
         run.slots[0]["words"] = c
         w = run._walk_ms(reps=4)

@@ -10,7 +10,7 @@ from smcounter_amd.engine import DevBuf
 import bench_fa
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
-pads = [0, 8192, 18432, 38912]
+pads = [0, 3072, 6144, 8192, 12288]
 eng = engine.Engine(0)
 cfg = synth.CONFIGS["C3"]
 run = bench_fa.AlignmentRun(eng, cfg, synth.params_for(cfg), n, min(48, len(os.sched_getaffinity(0))), slots=1, place=0)
@@ -28,7 +28,7 @@ for k, c in enumerate(cands):
     print("hipMalloc #%-5d " % k + "".join("%12.3f" % x for x in row), flush=True)
 os.environ["SMC_BP_LDS_PAD"] = "0"
 # the same with parts of other sizes (rows of the sorted list per wavefront)
-parts = [128, 192, 256, 384, 512]
+parts = [256]
 print("allocation      " + "".join("%12s" % ("part %d" % p) for p in parts))
 for k, c in enumerate(cands):
     row = []
