@@ -406,6 +406,7 @@ void smc_mem_free(smc_ctx* ctx, void* p);
  * and keeps the fastest.  info (may be NULL): [0] the kept block's probe time in ms, [1] the slowest candidate's, [2] candidates
  * tried.  Freed with smc_mem_free. */
 int smc_mem_alloc_best(smc_ctx* ctx, int64_t bytes, int tries, void** out, float* info);
+/* (smc_mem_write_probe OVERWRITES [p, p + bytes) with its pattern: for blocks that hold nothing yet.) */
 int smc_mem_write_probe(smc_ctx* ctx, void* p, int64_t bytes, float* ms);
 /* page-locked host memory: copies to and from it run at the link's rate (pageable memory goes through a staging copy) */
 int smc_mem_alloc_host(smc_ctx* ctx, int64_t bytes, void** out);
