@@ -79,3 +79,46 @@ def test_alignments_to_planes_on_synthetic_runs(cfg_name, n_loci, tmp_path):
     want = oracle_lib.call_batch(db, abi.c_params(P), abi.ROW_DTYPE)[37:91]
     got = oracle_lib.call_batch(sub, abi.c_params(P), abi.ROW_DTYPE)
     assert got.tobytes() == want.tobytes()
+
+
+def test_variants_under_synthetic_alignments(tmp_path):
+    """smc_synth_alignments with alt_locus_frac / alt_af (round 5): the run does not depend on the thread count; variant sites
+    carry the transition in about alt_af of the molecules; the reads of a molecule agree; such loci reach filterVariants in the
+    oracle; the decoder's path sees the same batch (the run written as a BAM: its NM makes the same mismatch-ok bits)."""
+    import oracle_lib
+    cfg = synth.CONFIGS["X3"]
+    P = synth.params_for(cfg)
+    n = 320
+    A = synth.generate_alignments(cfg, n, P, nthreads=5)
+    B = synth.generate_alignments(cfg, n, P, nthreads=2)
+    assert all(np.array_equal(A[k], B[k]) for k in ("aln", "cig", "bq", "loc"))
+    plain = synth.generate_alignments(synth.CONFIGS["C3"], n, synth.params_for(synth.CONFIGS["C3"]), nthreads=3)
+    db = oracle_lib.aln_planes(A, P, 0, n, n_threads=4)
+    want = oracle_lib.call_batch_mt(db, abi.c_params(P), abi.ROW_DTYPE, 4)
+    applied = (want["cand"]["flt_applied"] != 0).any(axis=1)
+    assert 0.15 * n < applied.sum() < 0.5 * n                       # alt_locus_frac 0.3
+    l = int(np.flatnonzero(applied)[0])
+    c = want["cand"][l][0]
+    assert 0.02 < c["vmt"] / max(1, want["used_mt"][l]) < 0.3        # alt_af 0.1 of the barcodes
+    # the reference allele dominates everywhere, and a run without variants has no filtered locus
+    db0 = oracle_lib.aln_planes(plain, synth.params_for(synth.CONFIGS["C3"]), 0, n, n_threads=4)
+    w0 = oracle_lib.call_batch_mt(db0, abi.c_params(synth.params_for(synth.CONFIGS["C3"])), abi.ROW_DTYPE, 4)
+    assert not (w0["cand"]["flt_applied"] != 0).any()
+    # the mismatch count a mapper would report includes the variant bases: fewer alignments pass the 6 / 100 b threshold
+    assert ((A["aln"]["oflag"] & 16) != 0).mean() < ((plain["aln"]["oflag"] & 16) != 0).mean() - 0.02
+
+
+def test_traffic_records_are_tied_to_the_library_they_were_measured_on(tmp_path, monkeypatch):
+    """bench_fa.traffic_record: a PMC record of profiles/traffic.json is handed out only when its lib_sha16 is the hash of the
+    library that runs now."""
+    import json
+    import bench_fa
+    have = bench_fa.lib_sha16()
+    assert len(have) == 16
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    assert "lib_sha16" in t["fa:C3:200000"] and "lib_sha16" in t["C3:200000"]
+    rec, why = bench_fa.traffic_record("fa:C3:200000")
+    assert (rec is not None) == (t["fa:C3:200000"]["lib_sha16"] == have)
+    assert (why is None) == (rec is not None)
+    rec, why = bench_fa.traffic_record("no:such:key")
+    assert rec is None and "no PMC record" in why

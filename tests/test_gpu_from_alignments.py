@@ -143,3 +143,24 @@ def test_large_blocks_virtual_memory_backing_and_the_write_pattern_probe(engine0
     again.upload(src)
     assert (again.download(np.uint32, n) == src).all()
     again.free()
+
+
+@pytest.mark.parametrize("poison", [0xA5, 0xFF, 0x5A])
+def test_nothing_reads_scratch_this_run_has_not_written(engine0, monkeypatch, poison):
+    """The plane builder's scratch is recycled from run to run (a fresh allocation is zero, a recycled one is not).  Round 5's soak
+    (scripts/fa_soak.py) found a read with bq = minBQ - 1 at the first position of an alignment with a deletion INCLUDED when the
+    byte next to its quality - a pair of the second pool no copy covers - held 0x8D or more: the byte-lane add carried.  Here
+    the scratch is filled with a pattern before every run (SMC_BP_POISON_SCRATCH) on shapes either side of the sort thresholds,
+    with many general CIGARs and minBQ one above a quality that occurs: every row must still equal the oracle's."""
+    import dataclasses
+    from smcounter_amd.params import VcParams
+    monkeypatch.setenv("SMC_BP_POISON_SCRATCH", str(poison))
+    cores = len(os.sched_getaffinity(0))
+    for n_umi, rpb, nl, pdel, pins in ((73, 60, 420, 0.05, 0.0), (1500, 15, 100, 0.0, 0.2), (30, 10, 700, 0.1, 0.1)):
+        cfg = synth.SynthConfig("P", nl, n_umi, rpb, 4242 + n_umi, p_overlap=0.9, alt_locus_frac=0.5, alt_af=0.1)
+        P = VcParams(minBQ=13, minMQ=0, mtDepth=n_umi, rpb=float(rpb), hpLen=8, mismatchThr=100.0, mtDrop=0, maxMT=0, primerDist=20)
+        A = synth.generate_alignments(cfg, nl, P, p_del_aln=pdel, p_ins_aln=pins, p_clip=0.0)
+        rb, got = _gpu_rows(engine0, A, P)
+        want, fragile, pi_all, n_al = oracle_rows(A, P, nl, cores)
+        assert (rb.loci["n_alleles"] == n_al).all()
+        assert abi.compare_rows(got, want, PI_TOL, P_TOL, fragile, pi_all) == []
