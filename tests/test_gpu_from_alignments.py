@@ -151,10 +151,12 @@ def test_nothing_reads_scratch_this_run_has_not_written(engine0, monkeypatch, po
     (scripts/fa_soak.py) found a read with bq = minBQ - 1 at the first position of an alignment with a deletion INCLUDED when the
     byte next to its quality - a pair of the second pool no copy covers - held 0x8D or more: the byte-lane add carried.  Here
     the scratch is filled with a pattern before every run (SMC_BP_POISON_SCRATCH) on shapes either side of the sort thresholds,
-    with many general CIGARs and minBQ one above a quality that occurs: every row must still equal the oracle's."""
+    with many general CIGARs and minBQ one above a quality that occurs: every row must still equal the oracle's.  The blocks the
+    device-made launch plan takes (lists, the deep class's descriptors) get the same treatment (SMC_PLAN_POISON)."""
     import dataclasses
     from smcounter_amd.params import VcParams
     monkeypatch.setenv("SMC_BP_POISON_SCRATCH", str(poison))
+    monkeypatch.setenv("SMC_PLAN_POISON", str(poison ^ 0x7E))
     cores = len(os.sched_getaffinity(0))
     for n_umi, rpb, nl, pdel, pins in ((73, 60, 420, 0.05, 0.0), (1500, 15, 100, 0.0, 0.2), (30, 10, 700, 0.1, 0.1)):
         cfg = synth.SynthConfig("P", nl, n_umi, rpb, 4242 + n_umi, p_overlap=0.9, alt_locus_frac=0.5, alt_af=0.1)
