@@ -61,8 +61,11 @@ class AlignmentRun(object):
         self.d_ref = up(np.frombuffer(run_ref.encode(), np.uint8).copy())
         self.xcap = 4 * self.nl + 4096
         self.slots = []
+        # the read words between the walk and the locus kernels: 16 bits each (smc_read_word16) unless the engine has been told
+        # otherwise (SMC_WORD_BITS=32) or the run has no room in them (checked below: one build, then 32-bit words)
+        self.word_bits = 16 if (eng.word_bits == 16 and 0 <= params.minBQ <= 63) else 32
         for k in range(max(1, slots)):
-            S = {"words": DevBuf(eng, 4 * (self.ns + 64), walk_output=True), "uaux": [DevBuf(eng, 4 * (self.ns + self.nl + 64)) for _ in range(3)],
+            S = {"words": self._words_buf(), "uaux": [DevBuf(eng, 4 * (self.ns + self.nl + 64)) for _ in range(3)],
                  "d_loci": DevBuf(eng, self.nl * LOCUS_DTYPE.itemsize), "d_x": DevBuf(eng, 20 * self.xcap), "d_cnt": DevBuf(eng, 8),
                  "rows": DevBuf(eng, self.nl * abi.ROW_DTYPE.itemsize), "stream": None}
             if slots > 1:
@@ -83,6 +86,15 @@ class AlignmentRun(object):
         self.t = {"build_issue": 0.0, "descriptors_d2h": 0.0, "plan_create": 0.0, "run_issue": 0.0, "n": 0}
         self.placement = None
         self.active_slots = len(self.slots)            # (slots the steps alternate between: _place may leave it at one)
+        if self.word_bits == 16:
+            self.step(slot=0)
+            eng.L.smc_device_sync(eng.ctx)
+            if self.status()[1] & 32:                   # (an allele id beyond 15 or a quality beyond 63 somewhere in the run)
+                self.word_bits = 32
+                for S in self.slots:
+                    S["words"].free()
+                    S["words"] = self._words_buf()
+                self.words = self.slots[0]["words"]
         if place > 0:
             try:
                 self._place(place)
@@ -90,6 +102,12 @@ class AlignmentRun(object):
                 self.placement = {"note": "placement trials abandoned: %s" % e}
                 eng.trim()
             self.words = self.slots[0]["words"]
+
+    def _words_buf(self):
+        from smcounter_amd.engine import DevBuf
+        w = DevBuf(self.eng, (self.word_bits // 8) * (self.ns + 64), walk_output=True)
+        w.word_bits = self.word_bits
+        return w
 
     def _walk_ms(self, reps: int = 3) -> float:
         eng, L = self.eng, self.eng.L
@@ -115,12 +133,12 @@ class AlignmentRun(object):
             pass
         for i in range(extra):
             mb = (37, 301, 1024, 2500, 150, 4097, 611, 1777)[i % 8]
-            budget -= (mb << 20) + 4.0 * (self.ns + 64)
+            budget -= (mb << 20) + (self.word_bits // 8) * (self.ns + 64)
             if budget < 0:
                 break
             try:
                 spacers.append(DevBuf(eng, (mb << 20) + 4096))
-                cands.append(DevBuf(eng, 4 * (self.ns + 64)))
+                cands.append(self._words_buf())
             except Exception:                             # (memory is short: what has been allocated so far are the candidates)
                 break
         ms = []
@@ -172,7 +190,7 @@ class AlignmentRun(object):
         the word out; the alignment records, their row records (written once, read once per tile they touch - counted once)
         and CIGARs; umi_start and the descriptor per locus."""
         A = self.A
-        return 2.0 * self.reads + 4.0 * self.ns + (36.0 + 32.0) * len(A["aln"]) + float(A["cig"].nbytes) + 36.0 * self.nl
+        return 2.0 * self.reads + (self.word_bits // 8) * float(self.ns) + (36.0 + 32.0) * len(A["aln"]) + float(A["cig"].nbytes) + 36.0 * self.nl
 
     def step(self, keep_plan=False, rows=None, slot=None):
         """build -> descriptors -> plan -> run; everything the product path does between the decoder and the rows."""
@@ -187,10 +205,15 @@ class AlignmentRun(object):
         sp = ctypes.c_void_p(st.cuda_stream if st is not None else 0)
         words, uaux, d_loci = S["words"], S["uaux"], S["d_loci"]
         t0 = time.perf_counter()
-        _lib.check(L.smc_build_planes(eng.ctx, ctypes.byref(self.cp), ctypes.byref(self.bi), 0, 0, words.data_ptr(), None, None,
-                                      None, None, uaux[0].data_ptr(), uaux[1].data_ptr(),
-                                      uaux[2].data_ptr(), d_loci.data_ptr(), S["d_x"].data_ptr(), self.xcap,
-                                      S["d_cnt"].data_ptr(), sp), "smc_build_planes")
+        if self.word_bits == 16:
+            _lib.check(L.smc_build_planes_w16(eng.ctx, ctypes.byref(self.cp), ctypes.byref(self.bi), 0, 0, words.data_ptr(), uaux[0].data_ptr(),
+                                              uaux[1].data_ptr(), uaux[2].data_ptr(), d_loci.data_ptr(), S["d_x"].data_ptr(), self.xcap,
+                                              S["d_cnt"].data_ptr(), sp), "smc_build_planes_w16")
+        else:
+            _lib.check(L.smc_build_planes(eng.ctx, ctypes.byref(self.cp), ctypes.byref(self.bi), 0, 0, words.data_ptr(), None, None,
+                                          None, None, uaux[0].data_ptr(), uaux[1].data_ptr(),
+                                          uaux[2].data_ptr(), d_loci.data_ptr(), S["d_x"].data_ptr(), self.xcap,
+                                          S["d_cnt"].data_ptr(), sp), "smc_build_planes")
         t1 = time.perf_counter()
         if self.host_plan:
             d_loci.download(LOCUS_DTYPE, self.nl, out=self.lc)        # (behind the kernels on the default stream)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SMC_ABI_VERSION 6
+#define SMC_ABI_VERSION 7
 #define SMC_MAX_ALLELES 64 /* allele ids per locus; ids 0-5 are A,T,G,C,N,'DEL' */
 
 /* error codes */
@@ -117,6 +117,40 @@ SMC_HOST_DEVICE static inline uint32_t smc_class_bits(uint32_t cls) {
     if (cls >= SMC_N_READ_CLASS) return 0u;
     const int inc = cls < 6u ? (int)(cls & 1u) : (((cls - 6u) & 7u) >= 2u);
     return SMC_RW_OK | (inc ? SMC_RW_INC : 0u);
+}
+
+/* The read word in 16 bits (ABI 7): what smc_build_planes_w16 writes and smc_plan_run_words16 reads - the intermediate between the
+ * walk over the alignments and the locus kernels at half the bytes (the walk is bound by what it writes).  The same
+ * information as the 32-bit word, for runs whose allele ids stay below 16 and whose base qualities below 64 (a run that
+ * breaks either is reported - status bit 32 of smc_build_planes_w16 - and built with 32-bit words instead):
+ *   bits 0-3 allele id; bit 4 first read of its fragment at this locus; bit 5 included (incCond); bits 6-7 and 14-15 the low and
+ *   the high half of a 4-bit class index; bits 8-13 base quality.
+ * (included << 4 | class index) is the read class renumbered so that inclusion is a bit of its own (smc_class16 below:
+ *   not included: 0 inside a deletion, 1 + reverse at an insertion / deletion start, 3 + 2 * reverse + (bq < minBQ) on a base;
+ *   included:     0, 1 + reverse as above, 3 + 6 * reverse + (smc_read_class's sub - 2) on a base);
+ * "the class is a known one" (bit 18 of the 32-bit word) has no bit: the builder writes no other. */
+SMC_HOST_DEVICE static inline uint32_t smc_class16(uint32_t cls) {          /* smc_read_class's number -> included << 4 | index; 31: no class */
+    if (cls < 2u) return (cls & 1u) << 4;
+    if (cls < 6u) return ((cls & 1u) << 4) | (1u + ((cls - 2u) >> 1));
+    if (cls >= SMC_N_READ_CLASS) return 31u;
+    { const uint32_t rev = (cls - 6u) >> 3, sub = (cls - 6u) & 7u;
+      return sub < 2u ? 3u + 2u * rev + sub : 16u | (3u + 6u * rev + (sub - 2u)); }
+}
+SMC_HOST_DEVICE static inline uint32_t smc_class16_inv(uint32_t c16) {      /* and back; 31 for a code smc_class16 never returns */
+    const uint32_t inc = (c16 >> 4) & 1u, idx = c16 & 15u;
+    if (idx == 0u) return inc;
+    if (idx < 3u) return 2u + 2u * (idx - 1u) + inc;
+    if (!inc) return idx < 7u ? 6u + 8u * ((idx - 3u) >> 1) + ((idx - 3u) & 1u) : 31u;
+    return idx < 15u ? 6u + 8u * ((idx - 3u) / 6u) + 2u + (idx - 3u) % 6u : 31u;
+}
+/* a 32-bit read word (allele < 16, quality < 64, a known class) as a 16-bit one, and back */
+SMC_HOST_DEVICE static inline uint32_t smc_read_word16(uint32_t w) {
+    const uint32_t c = smc_class16(w >> SMC_RW_CLASS_SHIFT);
+    return (w & 15u) | ((w & SMC_RW_NF) ? 16u : 0u) | ((c >> 4) & 1u) << 5 | (c & 3u) << 6 | ((w >> 8) & 63u) << 8 | ((c >> 2) & 3u) << 14;
+}
+SMC_HOST_DEVICE static inline uint32_t smc_read_word32(uint32_t h) {
+    const uint32_t c16 = ((h >> 5) & 1u) << 4 | ((h >> 6) & 3u) | ((h >> 14) & 3u) << 2, cls = smc_class16_inv(c16);
+    return (h & 15u) | ((h >> 8) & 63u) << 8 | ((h & 16u) ? SMC_RW_NF : 0u) | smc_class_bits(cls) | cls << SMC_RW_CLASS_SHIFT;
 }
 
 /* The numeric arguments vc() receives (smCounter.py:274) that the device path needs, plus the two
@@ -331,6 +365,10 @@ int smc_plan_run(smc_plan* plan, const smc_params* params, const uint32_t* meta,
  * words carry the fragment boundaries, not their count. */
 int smc_plan_run_words(smc_plan* plan, const smc_params* params, const uint32_t* words, const uint32_t* umi_start,
                        smc_row* rows, void* stream);
+/* The same on 16-bit read words (smc_read_word16; n_slots x uint16, a locus's first word 8-byte aligned: read_off4 counts
+ * quads of reads as before) - what smc_build_planes_w16 writes. */
+int smc_plan_run_words16(smc_plan* plan, const smc_params* params, const uint16_t* words16, const uint32_t* umi_start,
+                         smc_row* rows, void* stream);
 /* meta + frag planes of the plan's batch -> read words (device pointers; asynchronous on `stream`) */
 int smc_pack_words(smc_plan* plan, const uint32_t* meta, const uint32_t* frag, uint32_t* words, void* stream);
 
@@ -386,6 +424,14 @@ int smc_build_kernel_ms(smc_ctx* ctx, float* avg_ms, int32_t* n_samples);
 int smc_build_planes(smc_ctx* ctx, const smc_params* params, const smc_build_in* in, uint32_t slot_base, uint32_t umi_base,
                      uint32_t* words, uint32_t* meta, uint32_t* umi, uint32_t* frag, uint32_t* dist, uint32_t* umi_start,
                      uint32_t* u_gid, uint32_t* u_finc, smc_locus* loci, uint32_t* xlist, uint32_t xcap, uint32_t* counters, void* stream);
+
+/* The same run with the read words in 16 bits (smc_read_word16 above) and nothing else written but umi_start / u_gid / u_finc /
+ * loci / xlist: the walk stores half the bytes (the 3000x panel shape: 1.18 -> 1.00 ms) and the locus kernels load half.
+ * counters[1] has one more status bit, 32: the run has an allele id beyond 15 at some locus or a base quality beyond 63 - the
+ * words are not to be used, the caller builds the run again with smc_build_planes.  params->min_bq must lie in 0 .. 63. */
+int smc_build_planes_w16(smc_ctx* ctx, const smc_params* params, const smc_build_in* in, uint32_t slot_base, uint32_t umi_base,
+                         uint16_t* words16, uint32_t* umi_start, uint32_t* u_gid, uint32_t* u_finc, smc_locus* loci,
+                         uint32_t* xlist, uint32_t xcap, uint32_t* counters, void* stream);
 
 /* The context keeps the device blocks of destroyed plans for the next plan (at most 64 blocks / 8 GB; the oldest goes first).
  * smc_pool_trim waits for the plans' last runs and returns every pooled block to the runtime. */

@@ -12,9 +12,9 @@ LIB_PATH = os.environ.get("SMC_HIP_LIB") or os.path.join(HERE, "libsmcounter_hip
 
 SYMBOLS = ("smc_abi_version", "smc_last_error", "smc_row_size", "smc_locus_size", "smc_device_count",
            "smc_create", "smc_destroy", "smc_plan_create", "smc_plan_create_dev", "smc_plan_destroy", "smc_plan_info",
-           "smc_plan_run", "smc_plan_run_words", "smc_pack_words", "smc_plan_set_timing", "smc_plan_kernel_ms", "smc_call_batch_host", "smc_event_create", "smc_event_record",
+           "smc_plan_run", "smc_plan_run_words", "smc_plan_run_words16", "smc_pack_words", "smc_plan_set_timing", "smc_plan_kernel_ms", "smc_call_batch_host", "smc_event_create", "smc_event_record",
            "smc_event_elapsed_ms", "smc_event_destroy", "smc_class_table", "smc_wire_row_size", "smc_pack_rows", "smc_unpack_rows",
-           "smc_build_planes", "smc_build_max_depth", "smc_build_set_timing", "smc_build_kernel_ms", "smc_mem_alloc", "smc_mem_alloc_best", "smc_mem_write_probe", "smc_mem_free", "smc_mem_h2d", "smc_mem_d2h",
+           "smc_build_planes", "smc_build_planes_w16", "smc_build_max_depth", "smc_build_set_timing", "smc_build_kernel_ms", "smc_mem_alloc", "smc_mem_alloc_best", "smc_mem_write_probe", "smc_mem_free", "smc_mem_h2d", "smc_mem_d2h",
            "smc_mem_alloc_host", "smc_mem_free_host", "smc_pool_trim",
            "smc_device_sync")
 
@@ -65,6 +65,7 @@ def load(with_torch: bool = True):
     L.smc_plan_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i64)]
     L.smc_plan_run.argtypes = [vp, ctypes.POINTER(abi.SmcParams), vp, vp, vp, vp, vp, vp, vp]
     L.smc_plan_run_words.argtypes = [vp, ctypes.POINTER(abi.SmcParams), vp, vp, vp, vp]
+    L.smc_plan_run_words16.argtypes = [vp, ctypes.POINTER(abi.SmcParams), vp, vp, vp, vp]
     L.smc_pack_words.argtypes = [vp, vp, vp, vp, vp]
     L.smc_plan_set_timing.argtypes = [vp, ctypes.c_int]
     L.smc_plan_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(i32), ctypes.POINTER(i64),
@@ -90,12 +91,14 @@ def load(with_torch: bool = True):
     L.smc_build_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32)]
     L.smc_build_planes.argtypes = [vp, ctypes.POINTER(abi.SmcParams), ctypes.POINTER(abi.SmcBuildIn), ctypes.c_uint32,
                                    ctypes.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_uint32, vp, vp]
+    L.smc_build_planes_w16.argtypes = [vp, ctypes.POINTER(abi.SmcParams), ctypes.POINTER(abi.SmcBuildIn), ctypes.c_uint32,
+                                       ctypes.c_uint32, vp, vp, vp, vp, vp, vp, ctypes.c_uint32, vp, vp]
     L.smc_event_create.argtypes = [ctypes.POINTER(vp)]
     L.smc_event_record.argtypes = [vp, vp]
     L.smc_event_elapsed_ms.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_float)]
     L.smc_event_destroy.argtypes = [vp]
     L.smc_event_destroy.restype = None
-    if L.smc_abi_version() != 6:
+    if L.smc_abi_version() != 7:
         raise SmcError("ABI version mismatch")
     if L.smc_row_size() != abi.ROW_DTYPE.itemsize or L.smc_locus_size() != 32 or L.smc_wire_row_size() != abi.WIRE_DTYPE.itemsize:
         raise SmcError("struct layout mismatch between include/smcounter_hip.h and smcounter_amd/abi.py")

@@ -43,7 +43,8 @@ class ResidentBatch:
     n_host_runs: int = 0
     n_slots: int = 0
     n_ustart: int = 0
-    words: object = None       # the read words (one uint32 per read: what the locus kernels read), device buffer
+    words: object = None       # the read words (one per read: what the locus kernels read), device buffer; 32 bits each, or 16
+                               # (include/smcounter_hip.h: smc_read_word16) when its `word_bits` says so
 
     @property
     def n_loci(self) -> int:
@@ -56,6 +57,53 @@ class ResidentBatch:
         us = self.planes[4].download(np.uint32, self.n_ustart)
         return DeviceBatch(loci=self.loci.copy(), meta=m, umi=u, frag=f, dist=d, umi_start=us, chrom=list(self.chrom),
                            pos=self.pos.copy(), ref=list(self.ref), alleles=[list(t) for t in self.alleles])
+
+
+BUILD_ST_NARROW = 32           # smc_build_planes_w16's status bit: the run has no room in 16-bit read words
+NARROW = "narrow"              # what build_run answers then
+
+
+def class16_table() -> np.ndarray:
+    """smc_read_class's number -> smc_class16's code (included << 4 | index), 31 where there is no class (include/smcounter_hip.h)."""
+    t = np.full(32, 31, np.uint32)
+    for c in range(22):
+        if c < 2:
+            t[c] = (c & 1) << 4
+        elif c < 6:
+            t[c] = ((c & 1) << 4) | (1 + ((c - 2) >> 1))
+        else:
+            rev, sub = (c - 6) >> 3, (c - 6) & 7
+            t[c] = 3 + 2 * rev + sub if sub < 2 else 16 | (3 + 6 * rev + (sub - 2))
+    return t
+
+
+def words16_from_32(w: np.ndarray):
+    """32-bit read words -> 16-bit ones (smc_read_word16), or None when one of them has no room: an allele id beyond 15, a
+    quality beyond 63, a class that is none (a word of zero - the pad behind a locus's last read - stays zero)."""
+    w = np.asarray(w, np.uint32)
+    cls = w >> np.uint32(27)
+    c16 = class16_table()[cls]
+    real = w != 0
+    if bool(((((w & np.uint32(0xFF)) > 15) | (((w >> np.uint32(8)) & np.uint32(0xFF)) > 63) | (c16 == 31)) & real).any()):
+        return None
+    h = (w & np.uint32(15)) | ((w >> np.uint32(16)) & np.uint32(1)) << np.uint32(4) | ((c16 >> np.uint32(4)) & np.uint32(1)) << np.uint32(5) | \
+        (c16 & np.uint32(3)) << np.uint32(6) | ((w >> np.uint32(8)) & np.uint32(63)) << np.uint32(8) | ((c16 >> np.uint32(2)) & np.uint32(3)) << np.uint32(14)
+    return np.where(real, h, 0).astype(np.uint16)
+
+
+def words32_from_16(h: np.ndarray) -> np.ndarray:
+    """... and back (smc_read_word32): what tests compare with the host-built words."""
+    h = np.asarray(h, np.uint16).astype(np.uint32)
+    inv = np.full(32, 31, np.uint32)
+    t = class16_table()
+    for c in range(22):
+        inv[t[c]] = c
+    c16 = ((h >> np.uint32(5)) & np.uint32(1)) << np.uint32(4) | ((h >> np.uint32(6)) & np.uint32(3)) | ((h >> np.uint32(14)) & np.uint32(3)) << np.uint32(2)
+    cls = inv[c16]
+    inc = np.where(cls < 6, cls & 1, ((cls - 6) & 7) >= 2).astype(np.uint32)
+    w = (h & np.uint32(15)) | ((h >> np.uint32(8)) & np.uint32(63)) << np.uint32(8) | ((h >> np.uint32(4)) & np.uint32(1)) << np.uint32(16) | \
+        inc << np.uint32(17) | np.uint32(1 << 18) | cls << np.uint32(27)
+    return np.where(h != 0, w, 0).astype(np.uint32)
 
 
 def pack_words_host(meta: np.ndarray, frag: np.ndarray, loci: np.ndarray) -> np.ndarray:
@@ -120,7 +168,12 @@ def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], par
     while i < n:
         first = i
         planes = [DevBuf(eng, 4 * cap) if all_planes else None for k in range(4)]
-        words = DevBuf(eng, 4 * cap, walk_output=True)                # (a large one is chosen by the write-pattern probe: engine.DevBuf)
+        # 16-bit read words where nothing but the words is kept, until a run has no room in them (an allele id beyond 15, a
+        # quality beyond 63): that batch is then built again, and the rest of the file, with 32-bit words
+        bits = 16 if (not all_planes and eng.word_bits == 16 and 0 <= params.minBQ <= 63) else 32
+        words = DevBuf(eng, (bits // 8) * cap, walk_output=True)      # (a large one is chosen by the write-pattern probe: engine.DevBuf)
+        words.word_bits = bits
+        narrow = False
         uaux = [DevBuf(eng, 4 * (cap + 8192)) for _ in range(3)]      # umi_start, u_gid, u_finc
         LC, chroms, poss, refs, tables = [], [], [], [], []
         total = slots = n_loc = 0
@@ -149,6 +202,9 @@ def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], par
             if not force_host:
                 done = _device_run(bam, L, eng, cp, params, chrom, lo, hi, max_reads - total, nthreads, fasta, run_ref, [words] + planes, uaux,
                                    slots, umi_base, cap, max_depth)
+                if done == NARROW:
+                    narrow = True
+                    break
             if done is None:
                 # host builder (the run is not one the device path takes): same planes, uploaded
                 nl, hp, ustart, lc, tb = bam.planes_run(chrom, lo, hi, max_reads - total, params, run_ref, nthreads, fasta)
@@ -158,7 +214,13 @@ def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], par
                 for k in range(4):
                     if planes[k] is not None:
                         planes[k].upload(hp[k], 4 * slots)
-                words.upload(pack_words_host(hp[0], hp[2], lc), 4 * slots)
+                hw = pack_words_host(hp[0], hp[2], lc)
+                if bits == 16:
+                    hw = words16_from_32(hw)
+                    if hw is None:
+                        narrow = True
+                        break
+                words.upload(hw, (bits // 8) * slots)
                 uaux[0].upload(ustart, 4 * umi_base)
                 lc = lc.copy()
                 lc["read_off4"] += slots // 4
@@ -178,6 +240,12 @@ def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], par
             refs += list(run_ref[:nl]) + [""] * max(0, nl - len(run_ref))
             tables += tb
             i += nl
+        if narrow:
+            for b in [words] + uaux + [p for p in planes if p is not None]:
+                b.free()
+            eng.word_bits = 32
+            i = first
+            continue
         lc_all = LC[0] if len(LC) == 1 else np.concatenate(LC)
         uaux[1].free(); uaux[2].free()
         yield first, ResidentBatch(planes=planes + [uaux[0]], words=words, n_slots=slots, n_ustart=slots + n_loc + 1,
@@ -236,16 +304,25 @@ def build_run(A, L, eng, cp, params, chrom, lo, fasta, run_ref, planes, uaux, sl
     bi = abi.SmcBuildIn(d_aln.data_ptr(), d_cig.data_ptr(), d_bq.data_ptr(), d_loc.data_ptr(), d_ref.data_ptr(),
                         lo, nl, A["n_bc"], A["n_pair"], deepest, len(A["aln"]), loc_host.ctypes.data)
     pp = [t.data_ptr() if t is not None else None for t in planes]     # [words, meta, umi, frag, dist]
-    _lib.check(L.smc_build_planes(eng.ctx, ctypes.byref(cp), ctypes.byref(bi), slot_base, umi_base, pp[0], pp[1], pp[2], pp[3], pp[4],
-                                  uaux[0].data_ptr(),
-                                  uaux[1].data_ptr(), uaux[2].data_ptr(), d_loci.data_ptr(), d_x.data_ptr(), xcap,
-                                  d_cnt.data_ptr(), ctypes.c_void_p(0)), "smc_build_planes")
+    w16 = getattr(planes[0], "word_bits", 32) == 16
+    if w16:                                                            # (16-bit read words: nothing but the words is written)
+        assert all(p is None for p in pp[1:])
+        _lib.check(L.smc_build_planes_w16(eng.ctx, ctypes.byref(cp), ctypes.byref(bi), slot_base, umi_base, pp[0], uaux[0].data_ptr(),
+                                          uaux[1].data_ptr(), uaux[2].data_ptr(), d_loci.data_ptr(), d_x.data_ptr(), xcap,
+                                          d_cnt.data_ptr(), ctypes.c_void_p(0)), "smc_build_planes_w16")
+    else:
+        _lib.check(L.smc_build_planes(eng.ctx, ctypes.byref(cp), ctypes.byref(bi), slot_base, umi_base, pp[0], pp[1], pp[2], pp[3], pp[4],
+                                      uaux[0].data_ptr(),
+                                      uaux[1].data_ptr(), uaux[2].data_ptr(), d_loci.data_ptr(), d_x.data_ptr(), xcap,
+                                      d_cnt.data_ptr(), ctypes.c_void_p(0)), "smc_build_planes")
     t2 = time.perf_counter()
     cnt = d_cnt.download(np.uint32, 2)        # (a copy on the default stream: behind the kernel)
     t3 = time.perf_counter()
     if T is not None:
         T["upload+launch"] += t2 - t1; T["kernel (sync)"] += t3 - t2
     if int(cnt[1]) != 0 or int(cnt[0]) > xcap:
+        if w16 and (int(cnt[1]) & ~BUILD_ST_NARROW) == 0 and int(cnt[0]) <= xcap:
+            return NARROW                     # (an allele id beyond 15 or a quality beyond 63: the caller builds with 32-bit words)
         if int(cnt[1]) & 4:
             from .features import PileupError
             raise PileupError("base quality > 126 at %s:%d-%d" % (chrom, lo + 1, lo + nl))
@@ -318,12 +395,17 @@ def resident_from_alignments(A, eng, params, all_planes: bool = True, chrom: str
     nl, ns, lo = A["nl"], A["n_slots"], int(A["start0"])
     cap = ns + 64
     planes = [DevBuf(eng, 4 * cap) if all_planes else None for k in range(4)]
-    words = DevBuf(eng, 4 * cap, walk_output=True)
     uaux = [DevBuf(eng, 4 * (cap + nl + 8192)) for _ in range(3)]
     run_ref = synth.aln_ref_fetch(lo, lo + nl)
     ref = synth.CyclicRef()
-    done = build_run(A, L, eng, abi.c_params(params), params, chrom, lo, ref, run_ref, [words] + planes, uaux, 0, 0, cap + nl,
-                     L.smc_build_max_depth(), synth_allele_key(A), lambda gid: "B%d" % gid)
+    for bits in ((16, 32) if (not all_planes and eng.word_bits == 16 and 0 <= params.minBQ <= 63) else (32,)):
+        words = DevBuf(eng, (bits // 8) * cap, walk_output=True)
+        words.word_bits = bits
+        done = build_run(A, L, eng, abi.c_params(params), params, chrom, lo, ref, run_ref, [words] + planes, uaux, 0, 0, cap + nl,
+                         L.smc_build_max_depth(), synth_allele_key(A), lambda gid: "B%d" % gid)
+        if done != NARROW:
+            break
+        words.free()
     if done is None:
         raise RuntimeError("smc_build_planes did not take the run (status / size)")
     nl, ns, lc, tb = done

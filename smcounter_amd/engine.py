@@ -27,6 +27,7 @@ class DevBuf(object):
         # Sizes are rounded up to {1, 1.25, 1.5, 1.75} x 2^k and a freed allocation waits in the engine for the next request
         # of its size class (a batch allocates and frees some twenty buffers; the runtime's free synchronises the device)
         self.eng, self.nbytes = eng, int(nbytes)
+        self.word_bits = 32          # (an array of read words: 32, or 16 once smc_build_planes_w16 has filled it - Plan.run_words looks)
         self.cls = _size_class(self.nbytes)
         self.tuned = bool(walk_output) and eng.alloc_tries > 1 and self.cls >= TUNED_MIN_BYTES
         spare = (eng._spare_tuned if self.tuned else eng._spare).get(self.cls)
@@ -109,6 +110,9 @@ class Engine(object):
         # candidates per such block (1: take what comes).  About one allocation in eight is of the fast kind; the search stops at
         # the first it finds, a candidate costs ~ 5 ms of probing + its allocation (1-80 ms for 2.4 GB)
         self.alloc_tries = int(os.environ.get("SMC_ALLOC_TRIES", "12"))
+        # the read words between the plane builder and the locus kernels: 16 bits each (smc_read_word16) until a run has an allele
+        # id beyond 15 or a base quality beyond 63 - from then on 32 (devplanes.py; SMC_WORD_BITS=32: from the start)
+        self.word_bits = 32 if os.environ.get("SMC_WORD_BITS", "16") == "32" else 16
         self.alloc_log = []                   # what the probe saw, per chosen block
         self._pinned = {}                     # name -> (pointer, bytes) of page-locked staging memory
         self.last_rows = None                 # rows of the last vc.vc_resident call (pinned staging: valid until the next)
@@ -218,6 +222,10 @@ class Plan(object):
         if rows is None:
             rows = self.alloc_rows()
         cp = abi.c_params(params)
+        if getattr(words, "word_bits", 32) == 16:                     # (smc_read_word16: what smc_build_planes_w16 has written)
+            _lib.check(self.eng.L.smc_plan_run_words16(self.h, ctypes.byref(cp), words.data_ptr(), umi_start.data_ptr(), rows.data_ptr(),
+                                                       self._stream_ptr(stream)), "smc_plan_run_words16")
+            return rows
         _lib.check(self.eng.L.smc_plan_run_words(self.h, ctypes.byref(cp), words.data_ptr(), umi_start.data_ptr(), rows.data_ptr(),
                                                  self._stream_ptr(stream)), "smc_plan_run_words")
         return rows

@@ -81,12 +81,21 @@ def test_device_built_planes_and_kernels_against_the_reference(name, tmp_path, e
     with S/M/I/D/N/H, D next to I, two chromosomes, a locus deeper than 8192 reads, and loci over the barcode cap."""
     from smcounter_amd import devplanes, vc
     bam, fa, loci, P, expected = load_case(name, tmp_path)
-    text, n_dev = [], 0
-    for _, rb in devplanes.iter_resident_batches(bam, fa, loci, P, engine0, max_reads=40_000, nthreads=2):
-        text += list(vc.vc_resident(rb, P, fa, engine0))
-        n_dev += rb.n_device_runs
-    assert n_dev > 0
-    assert_rows(text, expected, "smc_bam_alignments -> k_build_planes -> k_call_v2")
+    # with the four raw-field planes beside the words (32-bit words), and the words alone - the command line's way: 16-bit words
+    # (smc_build_planes_w16 -> smc_plan_run_words16) until a run has no room in them, 32-bit from there on
+    bits_seen = set()
+    for all_planes in (True, False):
+        engine0.word_bits = 16
+        text, n_dev = [], 0
+        for _, rb in devplanes.iter_resident_batches(bam, fa, loci, P, engine0, max_reads=40_000, nthreads=2, all_planes=all_planes):
+            text += list(vc.vc_resident(rb, P, fa, engine0))
+            n_dev += rb.n_device_runs
+            bits_seen.add((all_planes, rb.words.word_bits))
+        assert n_dev > 0
+        assert_rows(text, expected, "smc_bam_alignments -> k_build_planes -> k_call_v2 (all_planes=%s)" % all_planes)
+    engine0.word_bits = 16
+    print(name, "word bits used:", sorted(bits_seen))
+    assert (True, 32) in bits_seen and ((False, 16) in bits_seen or (False, 32) in bits_seen)
 
 
 @pytest.mark.gpu

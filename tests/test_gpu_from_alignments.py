@@ -166,3 +166,62 @@ def test_nothing_reads_scratch_this_run_has_not_written(engine0, monkeypatch, po
         want, fragile, pi_all, n_al = oracle_rows(A, P, nl, cores)
         assert (rb.loci["n_alleles"] == n_al).all()
         assert abi.compare_rows(got, want, PI_TOL, P_TOL, fragile, pi_all) == []
+
+
+def _with_word_bits(eng, bits, fn):
+    old = eng.word_bits
+    eng.word_bits = bits
+    try:
+        return fn()
+    finally:
+        eng.word_bits = old
+
+
+def test_the_16_bit_read_words_are_the_32_bit_ones(engine0):
+    """smc_build_planes_w16 against smc_build_planes on the same run (general CIGARs, insertions, deletions, clips, a variant
+    under the reads, a locus window either side of the sort thresholds): every 16-bit word is smc_read_word16 of the 32-bit one,
+    umi_start and the descriptors are the same bytes, and so are the rows of smc_plan_run_words16 and smc_plan_run_words."""
+    from smcounter_amd import devplanes
+    from smcounter_amd.params import VcParams
+    for n_umi, rpb, nl in ((60, 40, 700), (900, 12, 150)):
+        cfg = synth.SynthConfig("W", nl, n_umi, rpb, 977 + n_umi, p_overlap=0.8, alt_locus_frac=0.4, alt_af=0.2)
+        P = VcParams(minBQ=20, minMQ=0, mtDepth=n_umi, rpb=float(rpb), hpLen=8, mismatchThr=100.0, mtDrop=0, maxMT=0, primerDist=20)
+        A = synth.generate_alignments(cfg, nl, P, p_del_aln=0.08, p_ins_aln=0.05, p_clip=0.2)
+        out = {}
+        for bits in (32, 16):
+            rb, rows = _with_word_bits(engine0, bits, lambda: _gpu_rows(engine0, A, P))
+            assert rb.words.word_bits == bits
+            out[bits] = (rb.words.download(np.uint16 if bits == 16 else np.uint32, rb.n_slots), rb.planes[4].download(np.uint32, rb.n_ustart),
+                         rb.loci.copy(), rows)
+        w32, w16 = out[32][0], out[16][0]
+        assert (devplanes.words16_from_32(w32) == w16).all()
+        real = w16 != 0
+        assert (devplanes.words32_from_16(w16)[real] == w32[real]).all() and not w32[~real].any()
+        assert out[32][2].tobytes() == out[16][2].tobytes()
+        for L in out[32][2]:                     # (the entries between two loci's ranges are nobody's)
+            o, nu = int(L["umi_off"]), int(L["n_umi"])
+            assert (out[32][1][o:o + nu + 1] == out[16][1][o:o + nu + 1]).all()
+        assert out[32][3].tobytes() == out[16][3].tobytes()
+
+
+def test_a_run_without_room_in_16_bit_words_is_built_with_32(engine0):
+    """A base quality beyond 63 under a covered locus: smc_build_planes_w16 reports it (status bit 32), the caller builds the run
+    with 32-bit words, the rows are the oracle's."""
+    from smcounter_amd import devplanes
+    from smcounter_amd.params import VcParams
+    cores = len(os.sched_getaffinity(0))
+    P = VcParams(minBQ=20, minMQ=0, mtDepth=80, rpb=30.0, hpLen=8, mismatchThr=100.0, mtDrop=0, maxMT=0, primerDist=20)
+    cfg = synth.SynthConfig("N", 300, 80, 30, 4711, p_overlap=0.8, alt_locus_frac=0.3, alt_af=0.2)
+    # (a) one quality of 70 somewhere in the middle of the pool
+    A = synth.generate_alignments(cfg, 300, P, p_del_aln=0.05, p_ins_aln=0.0, p_clip=0.0)
+    a = A["aln"][len(A["aln"]) // 2]
+    A["bq"][2 * (int(a["seq_off"]) + int(a["l_seq"]) // 2) + 1] = 70
+    rb, got = _with_word_bits(engine0, 16, lambda: _gpu_rows(engine0, A, P))
+    assert rb.words.word_bits == 32
+    want, fragile, pi_all, n_al = oracle_rows(A, P, 300, cores)
+    assert abi.compare_rows(got, want, PI_TOL, P_TOL, fragile, pi_all) == []
+    # (more than sixteen alleles at a locus: tests/test_bam_golden.py's bam_deep case, through the decoder - its batch is built again)
+    # and a run that does fit stays in 16 bits
+    A = synth.generate_alignments(cfg, 300, P, p_del_aln=0.05, p_ins_aln=0.0, p_clip=0.0)
+    rb, got = _with_word_bits(engine0, 16, lambda: _gpu_rows(engine0, A, P))
+    assert rb.words.word_bits == 16

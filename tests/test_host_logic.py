@@ -160,7 +160,8 @@ def test_abi_library_loads_and_exports_every_declared_symbol():
     L = _lib.load()
     hdr = open(os.path.join(ROOT, "include", "smcounter_hip.h")).read()
     declared = set(re.findall(r"\b(smc_[a-z_0-9]+)\s*\(", hdr))
-    declared -= {"smc_ctx", "smc_plan", "smc_read_class", "smc_class_bits", "smc_param_fingerprint"}      # (static inline helpers)
+    declared -= {"smc_ctx", "smc_plan", "smc_read_class", "smc_class_bits", "smc_param_fingerprint", "smc_class16", "smc_class16_inv",
+                 "smc_read_word16", "smc_read_word32"}                                                      # (static inline helpers)
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert getattr(L, name) is not None
@@ -665,3 +666,41 @@ def test_unpack_shard_gives_every_locus_its_own_allele_list():
     _, _, alleles = dist.unpack_shard(block)
     alleles[0].append("x")
     assert alleles[2] == base and alleles[1] == base + ["INS|A|AT"]
+
+
+def test_the_16_bit_read_word_holds_what_the_32_bit_one_does(tmp_path):
+    """include/smcounter_hip.h: smc_read_word16 / smc_read_word32 (what the device builder writes and the locus kernels read since
+    ABI 7) against each other over every class, allele < 16, quality < 64 and both fragment bits - compiled from the header with
+    gcc - and against devplanes' numpy forms of the same (what the tests unpack device-built words with)."""
+    import subprocess
+    from smcounter_amd import devplanes
+    src = tmp_path / "w16.c"
+    src.write_text('#include "smcounter_hip.h"\n'
+                   'unsigned w16(unsigned w) { return smc_read_word16(w); }\nunsigned w32(unsigned h) { return smc_read_word32(h); }\n'
+                   'unsigned c16(unsigned c) { return smc_class16(c); }\nunsigned c16i(unsigned c) { return smc_class16_inv(c); }\n'
+                   'unsigned bits(unsigned c) { return smc_class_bits(c); }\n')
+    so = str(tmp_path / "w16.so")
+    subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"), "-o", so, str(src)])
+    C = ctypes.CDLL(so)
+    for f in (C.w16, C.w32, C.c16, C.c16i, C.bits):
+        f.restype = ctypes.c_uint32; f.argtypes = [ctypes.c_uint32]
+    codes = [C.c16(c) for c in range(22)]
+    assert len(set(codes)) == 22 and max(codes) < 31 and all(C.c16i(codes[c]) == c for c in range(22))
+    assert all(((codes[c] >> 4) & 1) == ((C.bits(c) >> 17) & 1) for c in range(22))          # bit 4 of the code IS incCond
+    assert C.c16(22) == 31 and all(C.c16i(x) == 31 for x in range(32) if x not in codes)
+    assert (devplanes.class16_table()[:22] == np.array(codes)).all()
+    ws = []
+    for c in range(22):
+        for a in (0, 1, 5, 6, 15):
+            for q in (0, 13, 41, 63):
+                for nf in (0, 1):
+                    ws.append(a | q << 8 | nf << 16 | C.bits(c) | c << 27)
+    ws = np.array(ws, np.uint32)
+    hs = np.array([C.w16(int(w)) for w in ws], np.uint32)
+    assert (hs < 65536).all()
+    assert (np.array([C.w32(int(h)) for h in hs], np.uint32) == ws).all()
+    real = hs != 0          # (the word of zero - 'A' inside a deletion, not included, quality 0: no read - is the pad behind a locus's last read)
+    assert (devplanes.words16_from_32(ws) == hs).all() and (devplanes.words32_from_16(hs.astype(np.uint16))[real] == ws[real]).all()
+    assert int((~real).sum()) == 1
+    for bad in (16 | C.bits(6) | 6 << 27, 64 << 8 | C.bits(6) | 6 << 27, 3 | 25 << 27):     # allele 16, quality 64, no class
+        assert devplanes.words16_from_32(np.array([bad], np.uint32)) is None
