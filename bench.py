@@ -409,10 +409,12 @@ def main():
             "config": {"workload": "%s: %d loci%s x %d reads (%d UMIs x %d rpb), seed %d; as ALIGNMENTS resident in HBM: %s"
                        % (cfg.name, n_loc, "/GPU" if a.scaling == "weak" else " in total", cfg.depth, cfg.n_umi, cfg.rpb, cfg.seed,
                           bench_fa.describe(run, a.config)),
-                       "step": "smc_build_planes (sort, count, the walk that writes one word per pileup read) -> smc_plan_create_dev -> "
-                               "smc_plan_run_words (k_call_v2 + k_filter_loci) -> rows in HBM" + ((" -> %s rows gathered to rank 0"
+                       "step": ("smc_build_planes_w16 (sort, count, the walk that writes one 16-bit word per pileup read) -> smc_plan_create_dev -> "
+                                "smc_plan_run_words16 (k_call_v2 + k_filter_loci) -> rows in HBM" if run.word_bits == 16 else
+                                "smc_build_planes (sort, count, the walk that writes one word per pileup read) -> smc_plan_create_dev -> "
+                                "smc_plan_run_words (k_call_v2 + k_filter_loci) -> rows in HBM") + ((" -> %s rows gathered to rank 0"
                                % ("packed wire" if packed else "full")) if gather else ""),
-                       "loci_total": total_loci,
+                       "loci_total": total_loci, "read_word_bits": run.word_bits,
                        "parallelism": "loci sharded x%d, %s" % (world, ("%s rows gathered to rank 0" % ("packed wire" if packed else "full"))
                                                                  if gather else ("single GPU" if world == 1 else
                                                                                  "rows left in each rank's HBM (--rows resident)")),

@@ -317,8 +317,11 @@ def roofline_block(run: AlignmentRun, k_ms: float, k_n: int, cfg_name: str):
             "kernel_ms": k_ms, "kernel_samples": k_n, "needed_bytes_per_launch": need,
             "achieved": need / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": need / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "frac_basis": "needed bytes: 2 B in (base + quality) + 4 B out (the read word) per pileup read, alignment + row records "
-                          "and CIGARs once, umi_start + descriptor per locus; over the kernel's mean HIP-event duration",
+            "frac_basis": "needed bytes: 2 B in (base + quality) + %d B out (the read word) per pileup read, alignment + row records "
+                          "and CIGARs once, umi_start + descriptor per locus; over the kernel's mean HIP-event duration%s"
+                          % (run.word_bits // 8, " (16-bit read words since round 5's second half: a third fewer bytes to move than the 32-bit word's "
+                                                 "2 + 4 per read - the kernel's time fell by less than its bytes, so this fraction is LOWER than with "
+                                                 "32-bit words while the step is faster; SMC_WORD_BITS=32 runs the old format)" if run.word_bits == 16 else ""),
             "reads_per_s_kernel": run.reads / (k_ms * 1e-3),
             "traffic": traffic, "traffic_measured_in_run": False, **({"traffic_note": why} if why else {}),
             "traffic_source": ("profiles/traffic.json <- " + rec.get("source", "rocprofv3 --pmc")) if rec else None,
@@ -370,7 +373,8 @@ def run_leg(eng, cfg_name: str, n_loci: int, steps: int, warmup: int, blocks: in
     n = max(1, run.t["n"])
     out = {
         "workload": describe(run, cfg_name),
-        "step": "smc_build_planes (read words) -> smc_plan_create_dev (binning on the device) -> smc_plan_run_words -> rows in HBM",
+        "step": "smc_build_planes%s (read words) -> smc_plan_create_dev (binning on the device) -> smc_plan_run_words%s -> rows in HBM" % (
+            ("_w16", "16") if run.word_bits == 16 else ("", "")), "read_word_bits": run.word_bits,
         "value": run.nl * steps / el, "unit": "loci/s", "ms_per_step": el / steps * 1e3,
         "blocks_ms_per_step": [round(t / steps * 1e3, 3) for t in times],
         "slots": slots, "ms_per_step_one_at_a_time": serial, "placement": run.placement,

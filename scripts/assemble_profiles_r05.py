@@ -76,7 +76,7 @@ t["fa:C3:200000"] = {"hbm_bytes_per_launch": rd + wr, "fetch_size_kb": E["FETCH_
                                    "every request at 64 B: MI355X_MICROARCH.md, HBM); WRITE_SIZE as is",
                      "source": "profiles/r05_from_alignments_pmc.txt (python3 -m bench_fa under rocprofv3 --pmc, one pass per counter group; scripts/collect_round5.sh)",
                      "kernel": "k_bp_emit2", "needed_bytes_per_launch": need, "lib_sha16": lib}
-Ck = [k for k in f if k.startswith("void k_call_v2<64>")]
+Ck = [k for k in f if k.startswith("void k_call_v2<64")]
 if Ck:
     C = f[Ck[0]]
     cms = bench["step_breakdown"]["k_call_v2_ms"]
@@ -116,8 +116,9 @@ open(P + "/r05_place0_vs_place30.txt", "w").write(
     "# block the LIBRARY chose (smc_mem_alloc_best through engine.DevBuf(walk_output=True); the default) and with round 4's bench-side\n"
     "# trials on top (30 more allocations, each timed with the real walk, the two fastest kept)\n" + "\n".join(rows) + "\n")
 txt = ("# scripts/e2e_perf.py on the GPU box (round 5): the command-line path on synthetic BAMs, stage by stage\n")
-for n, label in (("2000", "2000 loci x 3000x, 60 reads per UMI"), ("20000", "20000 loci x 1000x, 20 reads per UMI"),
-                 ("500", "500 loci x 58000x, 9 reads per UMI (the depth of the reference's example run)")):
+for n, label in (("2000_3000", "2000 loci x 3000x, 60 reads per UMI"), ("20000_1000", "20000 loci x 1000x, 20 reads per UMI"),
+                 ("500_58000", "500 loci x 58000x, 9 reads per UMI (the depth of the reference's example run)"),
+                 ("2000_58000", "2000 loci x 58000x, 9 reads per UMI (the same depth, four times the loci: more than one run)")):
     if os.path.exists(O + "/e2e_%s.txt" % n):
         txt += "## " + label + "\n" + open(O + "/e2e_%s.txt" % n).read()
 open(P + "/r05_e2e_cli.txt", "w").write(txt)

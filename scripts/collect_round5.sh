@@ -11,9 +11,9 @@ for i in 1 2 3; do
 done
 timeout 600 python bench.py --scaling strong --config C4 --no-cpu-baseline --no-other-configs --steps 10 --warmup 3 > $O/bench_C4_strong_n1.json 2>/dev/null
 timeout 600 bash scripts/shapes_perf.sh 7 > $O/shapes.txt 2>&1
-for spec in "2000 3000 60" "20000 1000 20" "500 58000 9"; do
+for spec in "2000 3000 60" "20000 1000 20" "500 58000 9" "2000 58000 9"; do
   set -- $spec
-  timeout 600 python3 scripts/e2e_perf.py $1 $2 $3 2>&1 | grep -v -E "amdgpu|smc_bam|collect_reads" > $O/e2e_$1.txt
+  timeout 600 python3 scripts/e2e_perf.py $1 $2 $3 2>&1 | grep -v -E "amdgpu|smc_bam|collect_reads" > $O/e2e_$1_$2.txt
 done
 cd /tmp; export TMPDIR=/tmp; export PYTHONPATH=$R
 # kernel trace of the driver's command
@@ -44,4 +44,4 @@ find $O -name "*.csv" -size +300k -delete
 cd $R; SMC_BENCH_SHARE_GPU=1 timeout 600 python bench.py --gpus 2 --steps 10 --warmup 3 --loci-per-gpu 50000 --no-other-configs --no-cpu-baseline > $O/bench_2ranks_functional.json 2>/dev/null
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1
 sha256sum $R/smcounter_amd/libsmcounter_hip.so | cut -c1-16 > $O/lib_sha16.txt
-tail -3 $O/shapes.txt; head -14 $O/fa_kernels.txt; tail -3 $O/fa_timeline.txt; cat $O/e2e_500.txt | tail -8; wc -c $O/fa_pmc_summary.txt
+tail -3 $O/shapes.txt; head -14 $O/fa_kernels.txt; tail -3 $O/fa_timeline.txt; cat $O/e2e_500_58000.txt | tail -8; wc -c $O/fa_pmc_summary.txt

@@ -114,7 +114,7 @@ def call_shard(args, params: VcParams, loci, device: int, early=None):
         # default: the host decodes alignments, the GPU builds the planes from them (k_build_planes) and they stay in HBM
         from . import devplanes
         # (a batch only lives in HBM here - 16 B per read - so it can be eight times the host-built default)
-        batches = devplanes.iter_resident_batches(args.bamFile, ref, loci, params, eng, max_reads=8 * args.batchReads,
+        batches = devplanes.iter_resident_batches(args.bamFile, ref, loci, params, eng, max_reads=32 * args.batchReads,
                                                   nthreads=nthreads, all_planes=False)
         # (a batch ahead in a helper thread: decoding and building batch i + 1 overlaps the kernels and the strings of batch i;
         # the two threads use different staging buffers of the engine, device work is ordered by the default stream)
@@ -149,7 +149,7 @@ def call_shard_rows(args, params: VcParams, loci, device: int):
             for _, db in bamio.iter_device_batches_native(args.bamFile, ref, loci, params, max_reads=args.batchReads, nthreads=nthreads):
                 parts.append(eng.call_batch_host(db, params)); refs += list(db.ref); tables += list(db.alleles)
         else:
-            batches = devplanes.iter_resident_batches(args.bamFile, ref, loci, params, eng, max_reads=8 * args.batchReads,
+            batches = devplanes.iter_resident_batches(args.bamFile, ref, loci, params, eng, max_reads=32 * args.batchReads,
                                                       nthreads=nthreads, all_planes=False)
             for _, rb in _prefetch(batches, depth=1):
                 parts.append(vc.vc_resident_rows(rb, params, eng)); refs += list(rb.ref); tables += list(rb.alleles)

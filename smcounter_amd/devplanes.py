@@ -21,7 +21,6 @@ from . import _lib, abi, bamio
 from .features import LF_SAMPLED, LOCUS_DTYPE, USTART_DROPPED
 from .pileup import BASE_ALLELES
 
-READS_PER_BYTE = 2.5                       # pileup reads per compressed byte assumed when sizing a batch's first run
 _BASE_TABLE = list(BASE_ALLELES)           # the allele table of a locus that met only the six fixed keys (shared: read-only)
 
 
@@ -59,6 +58,8 @@ class ResidentBatch:
                            pos=self.pos.copy(), ref=list(self.ref), alleles=[list(t) for t in self.alleles])
 
 
+FIRST_RUN_WHOLE_BYTES = 48 << 20   # ... unless the whole stretch (up to 8192 loci) is no more than this in the file
+FIRST_RUN_LOCI = 64            # loci of a file's first run (iter_resident_batches): enough to learn the depth from
 BUILD_ST_NARROW = 32           # smc_build_planes_w16's status bit: the run has no room in 16-bit read words
 NARROW = "narrow"              # what build_run answers then
 
@@ -142,11 +143,15 @@ def pack_words_host(meta: np.ndarray, frag: np.ndarray, loci: np.ndarray) -> np.
     return np.where(valid, w, np.uint32(0)).astype(np.uint32)
 
 
-def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], params, eng, max_reads: int = 32_000_000,
+def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], params, eng, max_reads: int = 128_000_000,
                           nthreads: int = 0, force_host: bool = False, all_planes: bool = True):
     """BAM -> `ResidentBatch` chunks: same loci per chunk as bamio.iter_device_batches_native, planes built on the GPU.
     `all_planes=False`: only what the locus kernels read - the read words and umi_start - is built and kept (a fifth of the
-    device memory of a batch, a quarter of the builder's stores); the four raw-field planes (for checks) are then None."""
+    device memory of a batch, a quarter of the builder's stores); the four raw-field planes (for checks) are then None.
+    (Round 5 built and measured decoding run i + 1 on a helper thread - a second decoder handle, the streaming cursor handed
+    over - beside the upload, build and call of run i: at the example run's depth a run is 14 ms of decoding against 4 ms of
+    everything else, the helper's decodes were 30 % slower than the main thread's and its exit cost 40 ms per file: 13 k loci/s
+    against 22-24 k without.  Taken out again; what stayed is the sizing of the runs below.)"""
     from .engine import DevBuf
     L = eng.L
     bam = bamio.NativeBam(path)
@@ -165,108 +170,110 @@ def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], par
         stretch_end = ends[np.searchsorted(ends, np.arange(n))]
     cap = max_reads + (max_reads >> 3) + 65536
     per_locus = 0.0          # pileup reads per locus of the previous run: sizes the next run (a run is decoded as a whole)
-    while i < n:
-        first = i
-        planes = [DevBuf(eng, 4 * cap) if all_planes else None for k in range(4)]
-        # 16-bit read words where nothing but the words is kept, until a run has no room in them (an allele id beyond 15, a
-        # quality beyond 63): that batch is then built again, and the rest of the file, with 32-bit words
-        bits = 16 if (not all_planes and eng.word_bits == 16 and 0 <= params.minBQ <= 63) else 32
-        words = DevBuf(eng, (bits // 8) * cap, walk_output=True)      # (a large one is chosen by the write-pattern probe: engine.DevBuf)
-        words.word_bits = bits
-        narrow = False
-        uaux = [DevBuf(eng, 4 * (cap + 8192)) for _ in range(3)]      # umi_start, u_gid, u_finc
-        LC, chroms, poss, refs, tables = [], [], [], [], []
-        total = slots = n_loc = 0
-        n_dev = n_host = 0
-        while i < n and total < max_reads:
-            chrom = loci[i][0]
-            j = i
-            # (the decoder inflates everything up to the run's end: a run much longer than what max_reads lets through
-            # would be decoded again by the next one)
-            span_cap = 65536 if per_locus <= 0 else int(max(1024, min(65536, 1.15 * (max_reads - total) / per_locus)))
-            if per_locus <= 0 and i == first:
-                # nothing decoded yet: the linear index tells how many compressed bytes the stretch holds; at READS_PER_BYTE
-                # pileup reads per byte (on the dense side of what BAMs of 100-150 bp reads give) that sizes the first run -
-                # too long a guess only means that the run stops at max_reads and the rest is decoded again
+
+    def span_of(i, total, per_locus, first):
+        """The run that starts at locus i of a batch that holds `total` reads so far: (chrom, lo, hi, reads it may take)."""
+        chrom = loci[i][0]
+        # (the decoder inflates everything up to the run's end: a run much longer than what max_reads lets through
+        # would be decoded again by the next one)
+        # (the floor was 1024 loci and the factor 1.15 until round 5: at the example run's 58,000x a batch's first run took 550
+        # loci, its second was asked for 1024 - half a 2000-locus file inflated and parsed - to take the 51 the batch still had room for)
+        span_cap = 65536 if per_locus <= 0 else int(max(64, min(65536, 1.02 * (max_reads - total) / per_locus)))
+        if per_locus <= 0 and i == first:
+            # nothing decoded yet: a short first run tells the depth, the runs after it are sized by it.  (Until round 5 the first
+            # run was sized from the compressed bytes the linear index gives for the stretch, at 2.5 pileup reads per
+            # byte: on the 58,000x fixture that asked for all 2000 loci - 40 ms of decoding - to keep the 550 a batch has room for.)
+            # A stretch whose compressed bytes are few (the linear index knows) is taken whole: decoding all of it costs less than a
+            # run of its own for the first loci would.
+            span_cap = FIRST_RUN_LOCI
+            jj = min(int(stretch_end[i]), i + 8192 - 1)
+            nb = bam.span_bytes(chrom, int(pos_all[i]) - 1, int(pos_all[jj]))
+            if 0 <= nb < FIRST_RUN_WHOLE_BYTES or os.environ.get("SMC_FIRST_RUN_8192"):          # (the switch: measurement)
                 span_cap = 8192
-                jj = min(int(stretch_end[i]), i + 65536 - 1)
-                nb = bam.span_bytes(chrom, int(pos_all[i]) - 1, int(pos_all[jj]))
-                if nb >= 0 and not os.environ.get("SMC_FIRST_RUN_8192"):     # (the switch: measurement)
-                    est = READS_PER_BYTE * nb
-                    span_cap = int(max(8192, min(65536, (jj - i + 1) * (0.9 * max_reads / est if est > 0.9 * max_reads else 1.0))))
-            j = min(int(stretch_end[i]), i + span_cap - 1)
-            lo, hi = int(pos_all[i]) - 1, int(pos_all[j])
-            run_ref = fasta.fetch(chrom, lo, hi).upper()
-            umi_base = slots + n_loc
-            done = None
-            if not force_host:
-                done = _device_run(bam, L, eng, cp, params, chrom, lo, hi, max_reads - total, nthreads, fasta, run_ref, [words] + planes, uaux,
-                                   slots, umi_base, cap, max_depth)
-                if done == NARROW:
-                    narrow = True
-                    break
-            if done is None:
-                # host builder (the run is not one the device path takes): same planes, uploaded
-                nl, hp, ustart, lc, tb = bam.planes_run(chrom, lo, hi, max_reads - total, params, run_ref, nthreads, fasta)
-                ns = len(hp[0])
-                if slots + ns > cap or umi_base + len(ustart) > cap + 8192:
-                    raise bamio.BamError("run of %d read slots does not fit the device arena" % ns)
-                for k in range(4):
-                    if planes[k] is not None:
-                        planes[k].upload(hp[k], 4 * slots)
-                hw = pack_words_host(hp[0], hp[2], lc)
-                if bits == 16:
-                    hw = words16_from_32(hw)
-                    if hw is None:
+        j = min(int(stretch_end[i]), i + span_cap - 1)
+        return chrom, int(pos_all[i]) - 1, int(pos_all[j]), max_reads - total
+
+    import time
+    try:
+        while i < n:
+            first = i
+            planes = [DevBuf(eng, 4 * cap) if all_planes else None for k in range(4)]
+            # 16-bit read words where nothing but the words is kept, until a run has no room in them (an allele id beyond 15, a
+            # quality beyond 63): that batch is then built again, and the rest of the file, with 32-bit words
+            bits = 16 if (not all_planes and eng.word_bits == 16 and 0 <= params.minBQ <= 63) else 32
+            words = DevBuf(eng, (bits // 8) * cap, walk_output=True)      # (a large one is chosen by the write-pattern probe: engine.DevBuf)
+            words.word_bits = bits
+            narrow = False
+            uaux = [DevBuf(eng, 4 * (cap + 8192)) for _ in range(3)]      # umi_start, u_gid, u_finc
+            LC, chroms, poss, refs, tables = [], [], [], [], []
+            total = slots = n_loc = 0
+            n_dev = n_host = 0
+            while i < n and total < max_reads:
+                key = span_of(i, total, per_locus, first)
+                chrom, lo, hi = key[0], key[1], key[2]
+                run_ref = fasta.fetch(chrom, lo, hi).upper()
+                umi_base = slots + n_loc
+                done = None
+                if not force_host:
+                    T = _TIMES if os.environ.get("SMC_DEVPLANES_TIMING") else None
+                    t0 = time.perf_counter()
+                    A = bam.alignments_run(chrom, lo, hi, key[3], params, nthreads, host_array=eng.pinned)
+                    if T is not None:
+                        T["decode"] += time.perf_counter() - t0
+                    done = build_run(A, L, eng, cp, params, chrom, lo, fasta, run_ref, [words] + planes, uaux, slots, umi_base, cap, max_depth,
+                                     bam.allele_key, bam.barcode_name)
+                    if done == NARROW:
                         narrow = True
                         break
-                words.upload(hw, (bits // 8) * slots)
-                uaux[0].upload(ustart, 4 * umi_base)
-                lc = lc.copy()
-                lc["read_off4"] += slots // 4
-                lc["umi_off"] += umi_base
-                n_host += 1
-            else:
-                nl, ns, lc, tb = done
-                n_dev += 1
-            LC.append(lc)
-            if nl:
-                per_locus = max(1.0, float(lc["n_reads"].sum()) / nl)
-            slots += ns
-            n_loc += nl
-            total += int(lc["n_reads"].sum())
-            chroms += [chrom] * nl
-            poss.append(np.arange(lo + 1, lo + 1 + nl, dtype=np.int64))
-            refs += list(run_ref[:nl]) + [""] * max(0, nl - len(run_ref))
-            tables += tb
-            i += nl
-        if narrow:
-            for b in [words] + uaux + [p for p in planes if p is not None]:
-                b.free()
-            eng.word_bits = 32
-            i = first
-            continue
-        lc_all = LC[0] if len(LC) == 1 else np.concatenate(LC)
-        uaux[1].free(); uaux[2].free()
-        yield first, ResidentBatch(planes=planes + [uaux[0]], words=words, n_slots=slots, n_ustart=slots + n_loc + 1,
-                                   loci=lc_all, chrom=chroms, pos=poss[0] if len(poss) == 1 else np.concatenate(poss) if poss else np.zeros(0, np.int64),
-                                   ref=refs, alleles=tables,
-                                   n_device_runs=n_dev, n_host_runs=n_host)
-    bam.close()
-
-
-def _device_run(bam, L, eng, cp, params, chrom, lo, hi, max_reads, nthreads, fasta, run_ref, planes, uaux, slot_base, umi_base,
-                cap, max_depth):
-    """One run through smc_bam_alignments + smc_build_planes.  -> (n loci, slots, descriptors, allele tables) or None
-    when the run has to take the host builder."""
-    import time
-    T = _TIMES if os.environ.get("SMC_DEVPLANES_TIMING") else None
-    t0 = time.perf_counter()
-    A = bam.alignments_run(chrom, lo, hi, max_reads, params, nthreads, host_array=eng.pinned)
-    if T is not None:
-        T["decode"] += time.perf_counter() - t0
-    return build_run(A, L, eng, cp, params, chrom, lo, fasta, run_ref, planes, uaux, slot_base, umi_base, cap, max_depth,
-                     bam.allele_key, bam.barcode_name)
+                if done is None:
+                    # host builder (the run is not one the device path takes): same planes, uploaded
+                    nl, hp, ustart, lc, tb = bam.planes_run(chrom, lo, hi, max_reads - total, params, run_ref, nthreads, fasta)
+                    ns = len(hp[0])
+                    if slots + ns > cap or umi_base + len(ustart) > cap + 8192:
+                        raise bamio.BamError("run of %d read slots does not fit the device arena" % ns)
+                    for k in range(4):
+                        if planes[k] is not None:
+                            planes[k].upload(hp[k], 4 * slots)
+                    hw = pack_words_host(hp[0], hp[2], lc)
+                    if bits == 16:
+                        hw = words16_from_32(hw)
+                        if hw is None:
+                            narrow = True
+                            break
+                    words.upload(hw, (bits // 8) * slots)
+                    uaux[0].upload(ustart, 4 * umi_base)
+                    lc = lc.copy()
+                    lc["read_off4"] += slots // 4
+                    lc["umi_off"] += umi_base
+                    n_host += 1
+                else:
+                    nl, ns, lc, tb = done
+                    n_dev += 1
+                LC.append(lc)
+                if nl:
+                    per_locus = max(1.0, float(lc["n_reads"].sum()) / nl)
+                slots += ns
+                n_loc += nl
+                total += int(lc["n_reads"].sum())
+                chroms += [chrom] * nl
+                poss.append(np.arange(lo + 1, lo + 1 + nl, dtype=np.int64))
+                refs += list(run_ref[:nl]) + [""] * max(0, nl - len(run_ref))
+                tables += tb
+                i += nl
+            if narrow:
+                for b in [words] + uaux + [p for p in planes if p is not None]:
+                    b.free()
+                eng.word_bits = 32
+                i = first
+                continue
+            lc_all = LC[0] if len(LC) == 1 else np.concatenate(LC)
+            uaux[1].free(); uaux[2].free()
+            yield first, ResidentBatch(planes=planes + [uaux[0]], words=words, n_slots=slots, n_ustart=slots + n_loc + 1,
+                                       loci=lc_all, chrom=chroms, pos=poss[0] if len(poss) == 1 else np.concatenate(poss) if poss else np.zeros(0, np.int64),
+                                       ref=refs, alleles=tables,
+                                       n_device_runs=n_dev, n_host_runs=n_host)
+    finally:
+        bam.close()
 
 
 def build_run(A, L, eng, cp, params, chrom, lo, fasta, run_ref, planes, uaux, slot_base, umi_base, cap, max_depth,
