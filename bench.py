@@ -389,6 +389,13 @@ def main():
         run.step(rows=rows, slot=0)
     torch.cuda.synchronize()
     serial_ms = (time.perf_counter() - t_s) / a.steps * 1e3
+    # the same run with the read words in the other width (32 bits), the same way: what the 16-bit word bought on this box
+    other_width = None
+    if world == 1 and not a.no_other_configs and not os.environ.get("SMC_BENCH_NO_WIDTH_AB"):
+        try:
+            other_width = run.measure_other_word_width(a.steps, rows=rows)
+        except Exception as e:                                       # (memory short, ...: the headline does not depend on it)
+            other_width = {"error": str(e)}
     plan = run.step(keep_plan=True, rows=rows, slot=0)
     torch.cuda.synchronize()
     plan.set_timing(8)
@@ -428,7 +435,9 @@ def main():
                 "whole_step_on_survey_8d": {
                     "bytes_per_step": 16.0 * run.reads + 360.0 * run.nl,
                     "achieved": (16.0 * run.reads + 360.0 * run.nl) / (elapsed / a.steps) / 1e9, "unit": "GB/s",
-                    "frac": (16.0 * run.reads + 360.0 * run.nl) / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS}}),
+                    "frac": (16.0 * run.reads + 360.0 * run.nl) / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS},
+                # the step one at a time with the read words in the other width, same process, same inputs, right after the headline
+                **({"other_read_word_width_same_run": dict(other_width, ms_per_step_one_at_a_time_this_width=serial_ms)} if other_width else {})}),
             "step_breakdown": {"slots": a.slots, "ms_per_step_one_at_a_time": serial_ms, "placement": run.placement,
                                # what the library's write-pattern probe saw when it chose the blocks of the read words (one per slot)
                                "allocation": {"chosen_by": "smc_mem_alloc_best (engine.DevBuf(walk_output=True))", "tries": eng.alloc_tries,

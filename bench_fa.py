@@ -231,6 +231,36 @@ class AlignmentRun(object):
             return plan
         plan.close()
 
+    def measure_other_word_width(self, steps: int, rows=None):
+        """The same run, one step at a time on slot 0, with the read words in the OTHER width (32 bits where the run uses 16): the
+        walk's mean HIP-event time, the step's wall time and the walk's fraction of the roofline on ITS needed bytes - measured in
+        the same process right after the headline, so that the two formats can be compared on one box and one set of inputs."""
+        eng, L = self.eng, self.eng.L
+        keep_bits, keep_words = self.word_bits, self.slots[0]["words"]
+        self.word_bits = 32 if keep_bits == 16 else 16
+        try:
+            self.slots[0]["words"] = self._words_buf()
+            for _ in range(2):
+                self.step(rows=rows, slot=0)
+            L.smc_device_sync(eng.ctx)
+            _lib.check(L.smc_build_set_timing(eng.ctx, steps), "smc_build_set_timing")
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step(rows=rows, slot=0)
+            L.smc_device_sync(eng.ctx)
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            k_ms, k_n = ctypes.c_float(), ctypes.c_int32()
+            _lib.check(L.smc_build_kernel_ms(eng.ctx, ctypes.byref(k_ms), ctypes.byref(k_n)), "smc_build_kernel_ms")
+            L.smc_build_set_timing(eng.ctx, 0)
+            need = self.needed_bytes()
+            out = {"read_word_bits": self.word_bits, "ms_per_step_one_at_a_time": ms, "k_bp_emit2_ms": float(k_ms.value),
+                   "needed_bytes_per_launch": need, "frac": need / (float(k_ms.value) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "builder_status": self.status()}
+            self.slots[0]["words"].free()
+            return out
+        finally:
+            self.word_bits, self.slots[0]["words"] = keep_bits, keep_words
+
     def status(self):
         return self.d_cnt.download(np.uint32, 2).tolist()
 

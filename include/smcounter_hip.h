@@ -439,16 +439,15 @@ int smc_pool_trim(smc_ctx* ctx);
 
 /* Device memory for callers without a GPU runtime of their own (the Python command line uses these instead of importing
  * PyTorch: about a second of start-up): allocation, synchronous copies, device synchronisation. */
-/* smc_mem_alloc backs blocks of 256 MB and more by HIP virtual memory over physical handles of 64 MB each (SMC_VMM_CHUNK_MB=0 in
- * the environment: plain hipMalloc): which physical pages hold the read words of a batch moves the walk that writes them by 10 %
- * between hipMalloc allocations; this backing measured at or below the fastest of them in every process.
- * Pointers from it are freed with smc_mem_free only. */
+/* smc_mem_alloc is hipMalloc.  (For most of round 5 it backed blocks of 256 MB and more by HIP virtual memory over physical
+ * handles of 64 MB: such a range can LOSE what is written to it on this ROCm - csrc/host_abi.inc, vmm_alloc; scripts/vmm_stress.py;
+ * SMC_VMM_CHUNK_MB=<MB> in the environment brings it back for measurements.)  Pointers from it are freed with smc_mem_free only. */
 int smc_mem_alloc(smc_ctx* ctx, int64_t bytes, void** out);
 void smc_mem_free(smc_ctx* ctx, void* p);
 /* For an array the plane builder's walk WRITES (the read words of a batch): which physical pages hold it moves that kernel by up to
  * 10 % (the same from launch to launch; no counter of translation, L2 or request counts tells a fast allocation from a slow one,
  * but a write-only kernel with the walk's pattern does: smc_mem_write_probe).  smc_mem_alloc_best makes up to `tries` allocations
- * (virtual-memory ranges over handles of different sizes and plain blocks), times that pattern into each (~ 4 ms per candidate)
+ * (hipMalloc blocks, all held until the choice is made so that each gets other pages), times that pattern into each (~ 4 ms per candidate)
  * and keeps the fastest.  info (may be NULL): [0] the kept block's probe time in ms, [1] the slowest candidate's, [2] candidates
  * tried.  Freed with smc_mem_free. */
 int smc_mem_alloc_best(smc_ctx* ctx, int64_t bytes, int tries, void** out, float* info);
