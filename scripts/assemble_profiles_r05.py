@@ -80,13 +80,16 @@ Ck = [k for k in f if k.startswith("void k_call_v2<64")]
 if Ck:
     C = f[Ck[0]]
     cms = bench["step_breakdown"]["k_call_v2_ms"]
-    cneed = bench["consumer_only"]["roofline"]["needed_bytes_per_launch"]
-    t_c, crd, cwr = reading(C, cneed, cms, "k_call_v2<64> (one wavefront per locus, 200,000 of them), same passes")
+    bits = bench["config"].get("read_word_bits", 32)
+    reads = bench["roofline"]["reads_per_s_kernel"] * bench["roofline"]["kernel_ms"] * 1e-3
+    # (consumer_only's figure is for 32-bit words: the step's own locus kernel reads 16-bit ones when the run is built that way)
+    cneed = bench["consumer_only"]["roofline"]["needed_bytes_per_launch"] - (4 - bits // 8) * reads
+    t_c, crd, cwr = reading(C, cneed, cms, "%s (one wavefront per locus, 200,000 of them; %d-bit read words), same passes" % (Ck[0].split("(")[0].replace("void ", ""), bits))
     head += "#\n" + t_c
-    t["C3:200000"] = {"hbm_bytes_per_launch": crd + cwr, "fetch_size_kb": C["FETCH_SIZE"], "write_size_kb": C["WRITE_SIZE"],
-                      "read_requests": {k: C[k] for k in C if k.startswith("TCC_EA0_RDREQ")},
-                      "correction": "as for k_bp_emit2", "source": "profiles/r05_from_alignments_pmc.txt (the locus kernel of the same step: the same launch as consumer_only's)",
-                      "kernel": "k_call_v2<64>", "needed_bytes_per_launch": cneed, "lib_sha16": lib}
+    t["fa:C3:200000:k_call_v2"] = {"hbm_bytes_per_launch": crd + cwr, "fetch_size_kb": C["FETCH_SIZE"], "write_size_kb": C["WRITE_SIZE"],
+                                   "read_requests": {k: C[k] for k in C if k.startswith("TCC_EA0_RDREQ")},
+                                   "correction": "as for k_bp_emit2", "source": "profiles/r05_from_alignments_pmc.txt (the locus kernel of the same step)",
+                                   "kernel": Ck[0].split("(")[0].replace("void ", ""), "needed_bytes_per_launch": cneed, "lib_sha16": lib}
 for k in ("C5:100000", "C2:10000"):          # (measured on round 3's library: bench.py no longer prints them - the hash differs)
     if k in t and "lib_sha16" not in t[k]:
         t[k]["lib_sha16"] = "(round 3's library)"
@@ -109,7 +112,9 @@ for kind in ("place0", "place30"):
             sb = d["step_breakdown"]
             rows.append("%-8s process %d: %6.2f M loci/s, %.3f ms per step, k_bp_emit2 %.3f ms; library's probe: %s%s" % (
                 "--place 0" if kind == "place0" else "--place 30", i, d["value"] / 1e6, d["ms_per_step"], d["roofline"]["kernel_ms"],
-                ", ".join("%.3f of %.3f ms (%d tried)" % (b["probe_ms_kept"], b["probe_ms_slowest"], b["candidates"]) for b in sb["allocation"]["blocks"]),
+                (lambda B: ", ".join("%.3f of %.3f ms (%d tried)" % (b["probe_ms_kept"], b["probe_ms_slowest"], b["candidates"]) for b in B[:2]) +
+                           ("" if len(B) <= 2 else "; %d more blocks for the trials, kept %.3f-%.3f ms" % (
+                               len(B) - 2, min(b["probe_ms_kept"] for b in B[2:]), max(b["probe_ms_kept"] for b in B[2:]))))(sb["allocation"]["blocks"]),
                 ("; bench-side walk times %s" % sb["placement"]["walk_ms_by_allocation"]) if sb.get("placement") and "walk_ms_by_allocation" in sb["placement"] else ""))
 open(P + "/r05_place0_vs_place30.txt", "w").write(
     "# bench.py --no-cpu-baseline --no-other-configs --no-parity in fresh processes on one box (scripts/collect_round5.sh): the read words in the\n"

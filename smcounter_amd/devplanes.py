@@ -58,7 +58,7 @@ class ResidentBatch:
                            pos=self.pos.copy(), ref=list(self.ref), alleles=[list(t) for t in self.alleles])
 
 
-FIRST_RUN_WHOLE_BYTES = 48 << 20   # ... unless the whole stretch (up to 8192 loci) is no more than this in the file
+FIRST_RUN_WHOLE_BYTES = 48 << 20   # ... unless the whole stretch (up to 65536 loci) is no more than this in the file
 FIRST_RUN_LOCI = 64            # loci of a file's first run (iter_resident_batches): enough to learn the depth from
 BUILD_ST_NARROW = 32           # smc_build_planes_w16's status bit: the run has no room in 16-bit read words
 NARROW = "narrow"              # what build_run answers then
@@ -186,9 +186,11 @@ def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], par
             # A stretch whose compressed bytes are few (the linear index knows) is taken whole: decoding all of it costs less than a
             # run of its own for the first loci would.
             span_cap = FIRST_RUN_LOCI
-            jj = min(int(stretch_end[i]), i + 8192 - 1)
+            jj = min(int(stretch_end[i]), i + 65536 - 1)
             nb = bam.span_bytes(chrom, int(pos_all[i]) - 1, int(pos_all[jj]))
-            if 0 <= nb < FIRST_RUN_WHOLE_BYTES or os.environ.get("SMC_FIRST_RUN_8192"):          # (the switch: measurement)
+            if 0 <= nb < FIRST_RUN_WHOLE_BYTES:
+                span_cap = 65536
+            if os.environ.get("SMC_FIRST_RUN_8192"):                                             # (the switch: measurement)
                 span_cap = 8192
         j = min(int(stretch_end[i]), i + span_cap - 1)
         return chrom, int(pos_all[i]) - 1, int(pos_all[j]), max_reads - total
