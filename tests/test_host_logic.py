@@ -704,3 +704,14 @@ def test_the_16_bit_read_word_holds_what_the_32_bit_one_does(tmp_path):
     assert int((~real).sum()) == 1
     for bad in (16 | C.bits(6) | 6 << 27, 64 << 8 | C.bits(6) | 6 << 27, 3 | 25 << 27):     # allele 16, quality 64, no class
         assert devplanes.words16_from_32(np.array([bad], np.uint32)) is None
+
+
+def test_16_bit_builder_refuses_a_min_bq_it_has_no_room_for():
+    """smc_build_planes_w16: a read inside a deletion carries minBQ as its quality - six bits (no GPU needed: the argument checks
+    come first)."""
+    L = _lib.load()
+    cp = abi.c_params(VcParams(minBQ=64))
+    dummy = ctypes.c_void_p(0x1000)
+    rc = L.smc_build_planes_w16(None, ctypes.byref(cp), None, 0, 0, dummy, None, None, None, None, None, 0, None, None)
+    assert rc != 0 and b"minBQ 64" in L.smc_last_error()
+    assert L.smc_build_planes_w16(None, ctypes.byref(cp), None, 0, 0, None, None, None, None, None, None, 0, None, None) != 0     # no words array
