@@ -255,3 +255,24 @@ def test_a_run_without_room_in_16_bit_words_is_built_with_32(engine0):
     A = synth.generate_alignments(cfg, 300, P, p_del_aln=0.05, p_ins_aln=0.0, p_clip=0.0)
     rb, got = _with_word_bits(engine0, 16, lambda: _gpu_rows(engine0, A, P))
     assert rb.words.word_bits == 16
+
+
+def test_filter_tallies_by_their_own_kernel_give_the_same_rows(engine0, monkeypatch):
+    """The eight tallies only filterVariants reads are taken by the locus's own workgroup at the tail of its chain - or, in a batch
+    with loci of the deep class, by k_filter_tallies over the whole chip afterwards (wavefront-items of 4,096-read slices, integer
+    adds into the rows): the same bytes either way, on 3,000-read loci (SMC_TALLIES_LATER forces the kernel) and on loci of the
+    deep class (where it is the default; SMC_TALLIES_LATER=0 forces the workgroup's own pass)."""
+    for name, nl in (("X3", 3000), ("EX", 120)):
+        cfg = synth.CONFIGS[name]
+        P = synth.params_for(cfg)
+        A = synth.generate_alignments(cfg, nl, P)
+        out = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("SMC_TALLIES_LATER", mode)
+            rb, got = _gpu_rows(engine0, A, P)
+            out[mode] = got
+        monkeypatch.delenv("SMC_TALLIES_LATER")
+        rb, dflt = _gpu_rows(engine0, A, P)
+        assert out["0"].tobytes() == out["1"].tobytes() == dflt.tobytes()
+        flt = (dflt["cand"]["flt_applied"] != 0).any(axis=1)
+        assert int(flt.sum()) >= nl // 8 and int(dflt["ref_tal"][flt][:, 1:9].sum()) > 0
