@@ -352,6 +352,8 @@ def roofline_block(run: AlignmentRun, k_ms: float, k_n: int, cfg_name: str):
                           % (run.word_bits // 8, " (16-bit read words since round 5's second half: a third fewer bytes to move than the 32-bit word's "
                                                  "2 + 4 per read - the kernel's time fell by less than its bytes, so this fraction is LOWER than with "
                                                  "32-bit words while the step is faster; SMC_WORD_BITS=32 runs the old format)" if run.word_bits == 16 else ""),
+            # (for comparison across rounds: the same launch priced on the bytes the 32-bit word needed - what rounds 4 and 5a quoted)
+            **({"frac_on_the_32_bit_words_bytes": (need + 2.0 * run.ns) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS} if run.word_bits == 16 else {}),
             "reads_per_s_kernel": run.reads / (k_ms * 1e-3),
             "traffic": traffic, "traffic_measured_in_run": False, **({"traffic_note": why} if why else {}),
             "traffic_source": ("profiles/traffic.json <- " + rec.get("source", "rocprofv3 --pmc")) if rec else None,
