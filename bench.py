@@ -236,10 +236,10 @@ def dry_main(a, rank, world):
         dist.barrier()
     el = time.perf_counter() - t0
     if rank == 0:
-        print(json.dumps({"metric": "loci/sec at fixed read-depth x rpb", "value": None, "unit": "loci/s", "n_gpus": world,
-                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / max(1, a.steps) * 1e3, "higher_is_better": True,
-                          "scaling": a.scaling, "vs_baseline": None, "dtype": "u8/u32 scan + f64 posterior", "data": "synthetic",
-                          "config": {"workload": "dry run: launch plumbing only (SMC_BENCH_DRY=1), no GPU work"}, "dry_run": True}), flush=True)
+        emit({"metric": "loci/sec at fixed read-depth x rpb", "value": None, "unit": "loci/s", "n_gpus": world,
+              "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / max(1, a.steps) * 1e3, "higher_is_better": True,
+              "scaling": a.scaling, "vs_baseline": None, "dtype": "u8/u32 scan + f64 posterior", "data": "synthetic",
+              "config": {"workload": "dry run: launch plumbing only (SMC_BENCH_DRY=1), no GPU work"}, "dry_run": True})
     if world > 1:
         dist.destroy_process_group()
 
@@ -493,10 +493,110 @@ def main():
                 o.pop(k, None)
             out["from_alignments"][name] = o
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+LINE_LIMIT = 4096            # the driver reads a bounded tail of stdout: a line beyond it is not a record (BENCH_r05: parsed null)
+
+
+def _r(x, sig=6):
+    """Numbers of the headline line at `sig` significant digits (the sidecar keeps them in full)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        return float("%.*g" % (sig, x)) if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d}
+
+
+def compact(out: dict) -> dict:
+    """The ONE line the driver records: the contract's keys, `roofline` and `cpu_baseline`, the parity counts and one short
+    list per other leg - everything else of `out` (the prose, the allocation log, the extra CPU legs, the per-leg rooflines)
+    goes to the sidecar `bench_detail.json` and to stderr."""
+    cfgk = out.get("config", {})
+    line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                       "vs_baseline", "dtype", "data"))
+    line["config"] = _pick(cfgk, ("workload", "step", "loci_total", "read_word_bits", "parallelism"))
+    for k in ("workload", "step"):                       # (the sidecar has the long form)
+        if k in line["config"] and len(line["config"][k]) > 260:
+            line["config"][k] = line["config"][k][:257] + "..."
+    if "blocks" in out:
+        line["blocks_ms_per_step"] = out["blocks"]["ms_per_step"]
+    rf = out.get("roofline")
+    if rf is not None:
+        line["roofline"] = _pick(rf, ("bound", "kernel", "kernel_ms", "kernel_samples", "needed_bytes_per_launch", "achieved", "peak",
+                                      "unit", "frac", "traffic", "hbm_bytes_per_launch_pmc"))
+        line["roofline"]["kernel"] = str(line["roofline"].get("kernel", "")).split(" (")[0]
+        if "whole_step_on_survey_8d" in rf:
+            line["roofline"]["whole_step_on_survey_8d"] = _pick(rf["whole_step_on_survey_8d"], ("bytes_per_step", "frac"))
+    sb = out.get("step_breakdown")
+    if sb is not None:
+        line["step_breakdown"] = _pick(sb, ("ms_per_step_one_at_a_time", "k_bp_emit2_ms", "k_call_v2_ms", "host_ms_per_step"))
+    cb = out.get("cpu_baseline")
+    if cb is not None:
+        line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind"))
+        line["cpu_baseline"]["sample"] = cb.get("sample_short") or str(cb.get("sample", ""))[:160]
+    for k in ("cpu_baseline_c_from_alignments", "cpu_baseline_object_adapter"):
+        if out.get(k) is not None:
+            line[k] = _pick(out[k], ("value", "cores"))
+    if out.get("parity") is not None:
+        line["parity"] = _pick(out["parity"], ("loci", "mismatches", "pi_max_abs_diff", "p_max_abs_diff", "near_tie_skipped",
+                                               "fragile_skipped", "loci_filtered", "fisher_tests_run"))
+    if out.get("gather_check") is not None:
+        line["gather_check"] = out["gather_check"]
+
+    def leg(o):          # [loci/s, ms per step, mismatches, Fisher tests run, fraction of the roofline (leg's own basis)]
+        par = o.get("parity") or {}
+        frac = (o.get("whole_step_on_survey_8d") or {}).get("frac")
+        if frac is None:
+            frac = (o.get("roofline") or {}).get("frac")
+        return [o.get("value"), o.get("ms_per_step"), par.get("mismatches"), par.get("fisher_tests_run"), frac]
+    if out.get("from_alignments"):
+        line["from_alignments"] = {k: leg(v) for k, v in out["from_alignments"].items()}
+        line["legs_are"] = "[loci/s, ms_per_step, parity mismatches, Fisher tests run, roofline frac]"
+    if out.get("consumer_only"):
+        line["consumer_only"] = leg(out["consumer_only"])
+    if out.get("other_configs"):
+        line["other_configs"] = {k: leg(v) for k, v in out["other_configs"].items()}
+    if out.get("dry_run"):
+        line["dry_run"] = True
+    line["detail"] = "bench_detail.json"
+    return _r(line)
+
+
+def emit(out: dict):
+    """Everything to the sidecar (and to stderr), the compact line LAST on stdout."""
+    text = json.dumps(out)
+    for path in (os.path.join(ROOT, "bench_detail.json"), os.path.join(ROOT, "gpurun_out", "bench_detail.json")):
+        try:
+            if os.path.isdir(os.path.dirname(path)):
+                with open(path, "w") as fh:
+                    fh.write(text + "\n")
+        except OSError as e:                               # (a read-only checkout: the line is still printed)
+            sys.stderr.write("bench.py: %s not written: %s\n" % (path, e))
+    sys.stderr.write(text + "\n")
+    sys.stderr.flush()
+    line = json.dumps(compact(out), separators=(",", ":"))
+    if len(line) > LINE_LIMIT:                             # never print a line the driver cannot record: drop the optional legs
+        c = compact(out)
+        for k in ("other_configs", "consumer_only", "step_breakdown", "blocks_ms_per_step", "from_alignments"):
+            c.pop(k, None)
+            line = json.dumps(c, separators=(",", ":"))
+            if len(line) <= LINE_LIMIT:
+                break
+    assert len(line) <= LINE_LIMIT, len(line)
+    sys.stdout.flush()
+    print(line, flush=True)
 
 
 class _TensorBuf(object):
@@ -613,6 +713,8 @@ def cpu_leg(a):
     per_core_pool = n_py / dt_py / phys
     return {
         "python_pool": {"value": n_py / dt_py, "unit": "loci/s", "cores": phys, "logical_cpus": cores, "kind": "port",
+                        "sample_short": "first %d loci of the workload, oracle/vc_port.py under multiprocessing.Pool(%d), one task per locus "
+                                        "(smCounter.py:683-685), %.1f s" % (n_py, cores, dt_py),
                         "per_physical_core": per_core_pool,
                         "ideal_all_cores": n_one / dt_one * phys,
                         "sample": "first %d loci of the same workload, pure-Python port oracle/vc_port.py under "
