@@ -444,7 +444,8 @@ def main():
                                               "blocks": list(eng.alloc_log)},
                                "k_bp_emit2_ms": k_ms.value, "k_call_v2_ms": c_ms,
                                "host_ms_per_step": {k: round(v / n_steps * 1e3, 3) for k, v in run.t.items() if k != "n"},
-                               "pileup_reads_per_s": run.reads * a.steps / elapsed, "builder_status": status},
+                               "pileup_reads_per_s": run.reads * a.steps / elapsed, "builder_status": status,
+                               "plans": bench_fa.plans_record(eng)},
             "p_value_note": "C3 has no locus that reaches filterVariants (parity.loci_filtered 0): the p-value half of the metric is "
                             "carried by from_alignments X3 / EX / C5 (the same step as the headline, variants under the reads) and by "
                             "other_configs X3 / EX / C5 (read words resident)",

@@ -83,6 +83,8 @@ class AlignmentRun(object):
         self.rows = S0["rows"]
         self.lc = np.empty(self.nl, LOCUS_DTYPE)
         self.host_plan = bool(os.environ.get("SMC_FA_HOST_PLAN"))      # (measurement: descriptors back to the host, smc_plan_create)
+        self.pace = not os.environ.get("SMC_FA_NO_PACE")
+        self.exact_plans = bool(os.environ.get("SMC_FA_EXACT_PLANS"))   # (measurement: every plan waits for its batch's own record, round 5's way)
         self.t = {"build_issue": 0.0, "descriptors_d2h": 0.0, "plan_create": 0.0, "run_issue": 0.0, "n": 0}
         self.placement = None
         self.active_slots = len(self.slots)            # (slots the steps alternate between: _place may leave it at one)
@@ -202,6 +204,12 @@ class AlignmentRun(object):
         S = self.slots[slot]
         self.last_slot = slot
         st = S["stream"]
+        # (nothing in a step waits for the device any more - smc_plan_create_dev_spec -, so the host paces itself: a slot is issued
+        # again only when its previous step is through; without that the host runs hundreds of steps ahead, the two streams' queues
+        # interleave as they like and the pool of plan blocks is exhausted - measured: X3 0.73 -> 2.3 ms per step)
+        if st is not None and self.pace:
+            if len(S.setdefault("done", [])) >= 2:          # (two steps of a slot may be in flight: the one running and the one queued behind it)
+                S["done"].pop(0).synchronize()
         sp = ctypes.c_void_p(st.cuda_stream if st is not None else 0)
         words, uaux, d_loci = S["words"], S["uaux"], S["d_loci"]
         t0 = time.perf_counter()
@@ -221,10 +229,17 @@ class AlignmentRun(object):
             plan = eng.make_plan(self.lc)
         else:
             t2 = t1
-            plan = eng.make_plan_dev(d_loci, self.nl, stream=st)      # binned where the descriptors are (waits for the builder)
+            # binned where the descriptors are; from the run's second step on without waiting for the builder (smc_plan_create_dev_spec:
+            # the launches sized from the step before - the same run: they fit; run_leg / bench.py check the device's count of misfits)
+            plan = eng.make_plan_dev(d_loci, self.nl, stream=st, spec_params=None if self.exact_plans else self.params)
         t3 = time.perf_counter()
         plan.run([words, uaux[0]], self.params, S["rows"] if rows is None else rows, stream=st if st is not None else 0)
         t4 = time.perf_counter()
+        if st is not None and self.pace:
+            import torch
+            ev = torch.cuda.Event()
+            ev.record(st)
+            S["done"].append(ev)
         T = self.t
         T["build_issue"] += t1 - t0; T["descriptors_d2h"] += t2 - t1; T["plan_create"] += t3 - t2; T["run_issue"] += t4 - t3; T["n"] += 1
         if keep_plan:
@@ -420,6 +435,7 @@ def run_leg(eng, cfg_name: str, n_loci: int, steps: int, warmup: int, blocks: in
         "builder_status": st,
         "generate_s": round(run.t_gen, 1),
     }
+    out["plans"] = plans_record(eng)
     if parity_loci:
         run.step(slot=0)
         L.smc_device_sync(eng.ctx)
@@ -428,6 +444,15 @@ def run_leg(eng, cfg_name: str, n_loci: int, steps: int, warmup: int, blocks: in
                                     chunk=int(max(200, min(20000, 60e6 // max(1.0, run.reads / run.nl)))))
     run.close()
     return out
+
+
+def plans_record(eng):
+    """Plans this engine has made without waiting for the device (smc_plan_create_dev_spec), how many of them went the exact way,
+    how many the DEVICE found not to fit their launches - such a step computed nothing: the measurement would be void."""
+    made, exact, misfit = eng.spec_counts()
+    if misfit:
+        raise SystemExit("bench: %d of %d plans made without the host did not fit their launches - those steps computed nothing" % (misfit, made))
+    return {"made_without_waiting_for_the_device": made, "made_the_exact_way": exact, "not_fitting": misfit}
 
 
 def describe(run: AlignmentRun, cfg_name: str) -> str:

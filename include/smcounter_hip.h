@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SMC_ABI_VERSION 7
+#define SMC_ABI_VERSION 8
 #define SMC_MAX_ALLELES 64 /* allele ids per locus; ids 0-5 are A,T,G,C,N,'DEL' */
 
 /* error codes */
@@ -344,6 +344,20 @@ void smc_plan_destroy(smc_plan* plan);
  * context may be made on different streams one after the other (the record they sum into is the context's: a plan's kernels wait
  * for the plan before it to be through with it); a plan is run by one stream at a time. */
 int smc_plan_create_dev(smc_ctx* ctx, const smc_locus* d_loci, int64_t n_loci, void* stream, smc_plan** out);
+/* (ABI 8) The same plan WITHOUT the host in the loop: nothing here waits for the device.  The launches are sized from the record of
+ * the context's last plan (scaled to this batch's loci, with room) instead of this batch's own, which the device sums while the
+ * host goes on; whether the batch FITS those sizes is decided on the device: one that does not launches nothing.  So, after the
+ * caller has synchronised the stream for the rows, smc_plan_spec_ok(plan, &ok) says whether they are this batch's (ok = 1) or the
+ * plan has to be made again - by this function, which then goes the exact way (as it does for a context's first plan: there is
+ * nothing to size it from), or by smc_plan_create_dev - and run again (ok = 0).  For callers that make plan after plan of batches of
+ * one kind - the runs of a BAM (smCounter.py:683-685 submits them one after the other), the steps of the bench: the host thread no
+ * longer waits for the build of the planes, the device no longer idles around the read-back.  `prm`: the parameters the planes were
+ * built with (every descriptor has to carry their fingerprint).  smc_plan_run (raw-field planes) is not for such a plan. */
+int smc_plan_create_dev_spec(smc_ctx* ctx, const smc_params* prm, const smc_locus* d_loci, int64_t n_loci, void* stream, smc_plan** out);
+int smc_plan_spec_ok(smc_plan* plan, int* ok);
+/* Plans made by smc_plan_create_dev_spec in this context, how many of them went the exact way, how many the device found not to
+ * fit (reads a counter on the device: synchronises it) - for a caller that destroys its plans unchecked (a benchmark loop). */
+int smc_plan_spec_counts(smc_ctx* ctx, int64_t* made, int64_t* exact, int64_t* not_fitting);
 /* number of kernel launches one smc_plan_run issues, and bytes of device scratch it holds */
 int smc_plan_info(const smc_plan* plan, int32_t* n_launches, int64_t* scratch_bytes);
 

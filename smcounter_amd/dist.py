@@ -4,9 +4,10 @@ The reference's only parallelism is a process pool over loci with results collec
 submission order (smCounter.py:683-685).  Loci share nothing, so here rank r of N calls a
 contiguous range of the ordered locus list on its own GPU and the fixed-width rows
 (include/smcounter_hip.h: smc_row) are gathered to rank 0 in rank order, which restores the
-submission order.  One collective per batch: a gather (variable block sizes are padded to the
-largest block; RCCL has no gatherv).  Works with the `nccl` (= RCCL) backend on GPUs and with
-`gloo` on CPU tensors (used by the tests).
+submission order.  One exchange per batch: equal shares (the bench) as a gather, shares of different
+sizes (the command line's split by reads) as grouped sends / receives at their own sizes - the
+gatherv RCCL does not have as a collective.  Works with the `nccl` (= RCCL) backend on GPUs and
+with `gloo` on CPU tensors (used by the tests).
 """
 from __future__ import annotations
 
@@ -42,22 +43,39 @@ def gather_rows(rows, gather_list: Optional[list], dst: int = 0):
     dist.gather(rows, gather_list if dist.get_rank() == dst else None, dst=dst)
 
 
-def gatherv_rows(rows, counts: Sequence[int], row_bytes: int, dst: int = 0):
-    """Variable-size gather: every rank pads its block to max(counts) rows; `dst` returns the
-    concatenation in rank order (a uint8 tensor), other ranks return None."""
+def _gatherv(payload, sizes: Sequence[int], dst: int):
+    """Blocks of `sizes[r]` elements from every rank r to `dst` - each at its own size, nothing padded: the ranks other than `dst`
+    post one send, `dst` one receive per peer that has something, as ONE group (torch.distributed.batch_isend_irecv: with the
+    `nccl` backend ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd - the gatherv RCCL does not have as a collective, SURVEY.md
+    8e; every peer's block travels its own xGMI link to `dst`).  -> list of tensors in rank order on `dst`, None elsewhere."""
     import torch
     import torch.distributed as dist
     world, rank = dist.get_world_size(), dist.get_rank()
-    mx = max(counts) * row_bytes
-    buf = rows
-    if rows.numel() < mx:
-        buf = torch.zeros(mx, dtype=rows.dtype, device=rows.device)
-        buf[:rows.numel()] = rows
-    glist = [torch.empty(mx, dtype=rows.dtype, device=rows.device) for _ in range(world)] if rank == dst else None
-    dist.gather(buf, glist, dst=dst)
-    if rank != dst:
+    ops, out = [], None
+    if rank == dst:
+        out = [payload if r == dst else torch.empty(int(sizes[r]), dtype=payload.dtype, device=payload.device) for r in range(world)]
+        ops = [dist.P2POp(dist.irecv, out[r], r) for r in range(world) if r != dst and sizes[r] > 0]
+    elif sizes[rank] > 0:
+        ops = [dist.P2POp(dist.isend, payload, dst)]
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return out
+
+
+def gatherv_rows(rows, counts: Sequence[int], row_bytes: int, dst: int = 0):
+    """Variable-size gather of row bytes: rank r hands over counts[r] rows (known to every rank: the shares of the locus list);
+    `dst` returns the concatenation in rank order (a uint8 tensor), other ranks return None.  Nothing is padded (round 6: an uneven
+    shard_by_reads split no longer ships the largest share's size from every rank)."""
+    import torch
+    import torch.distributed as dist
+    rank = dist.get_rank()
+    sizes = [int(c) * row_bytes for c in counts]
+    assert rows.numel() >= sizes[rank]
+    parts = _gatherv(rows[:sizes[rank]].contiguous(), sizes, dst)
+    if parts is None:
         return None
-    return torch.cat([g[:counts[r] * row_bytes] for r, g in enumerate(glist)])
+    return torch.cat(parts) if parts else rows[:0]
 
 
 def gather_strings(local: Sequence[str], dst: int = 0):
@@ -108,26 +126,16 @@ def unpack_shard(block: np.ndarray):
 
 def gatherv_bytes(payload, dst: int = 0):
     """Byte blocks of different sizes from every rank to `dst` (a list of uint8 tensors in rank order there, None elsewhere):
-    sizes first (one small all_gather), then ONE gather of blocks padded to the largest (RCCL has no gatherv).  `payload`: a
+    sizes first (one small all_gather), then the blocks as grouped sends / receives, each at its own size (_gatherv).  `payload`: a
     uint8 tensor on the device the backend moves (CPU for gloo, the rank's GPU for nccl)."""
     import torch
     import torch.distributed as dist
-    world, rank = dist.get_world_size(), dist.get_rank()
+    world = dist.get_world_size()
     size = torch.tensor([payload.numel()], dtype=torch.int64, device=payload.device)
     sizes = [torch.zeros_like(size) for _ in range(world)]
     dist.all_gather(sizes, size)
     sizes = [int(t.item()) for t in sizes]
-    mx = max(sizes)
-    buf = payload
-    if payload.numel() < mx:
-        buf = torch.zeros(mx, dtype=torch.uint8, device=payload.device)
-        buf[:payload.numel()] = payload
-    glist = [torch.empty(mx, dtype=torch.uint8, device=payload.device) for _ in range(world)] if rank == dst else None
-    if mx:
-        dist.gather(buf, glist, dst=dst)
-    if rank != dst:
-        return None
-    return [g[:sizes[r]] for r, g in enumerate(glist)]
+    return _gatherv(payload, sizes, dst)
 
 
 def all_gather_status(err: Optional[str]) -> List[Optional[str]]:

@@ -180,19 +180,39 @@ class Engine(object):
         return Plan(self, h, len(loci))
 
 
-    def make_plan_dev(self, d_loci, n_loci: int, stream=None):
+    def make_plan_dev(self, d_loci, n_loci: int, stream=None, spec_params: VcParams = None):
         """The plan of a batch whose descriptors are in HBM (`d_loci`: DevBuf / tensor of smc_locus, e.g. what smc_build_planes
-        wrote): binned on the device (smc_plan_create_dev), default stream.  `d_loci` must outlive the plan."""
+        wrote): binned on the device (smc_plan_create_dev), default stream.  `d_loci` must outlive the plan.
+        `spec_params` (the parameters the planes were built with): smc_plan_create_dev_spec - nothing waits for the device, the
+        launches are sized from the context's last plan; the caller asks `plan.ok()` once it has the rows and, on False, makes the
+        plan again and re-runs it."""
         h = ctypes.c_void_p()
         sp = ctypes.c_void_p(stream.cuda_stream if stream is not None else 0)     # (a torch stream, or the default one)
-        _lib.check(self.L.smc_plan_create_dev(self.ctx, d_loci.data_ptr(), int(n_loci), sp, ctypes.byref(h)),
-                   "smc_plan_create_dev")
+        if spec_params is not None:
+            cp = abi.c_params(spec_params)
+            _lib.check(self.L.smc_plan_create_dev_spec(self.ctx, ctypes.byref(cp), d_loci.data_ptr(), int(n_loci), sp, ctypes.byref(h)),
+                       "smc_plan_create_dev_spec")
+        else:
+            _lib.check(self.L.smc_plan_create_dev(self.ctx, d_loci.data_ptr(), int(n_loci), sp, ctypes.byref(h)),
+                       "smc_plan_create_dev")
         return Plan(self, h, int(n_loci))
+
+    def spec_counts(self):
+        """(plans made without the host, of those made the exact way, found not to fit on the device) - smc_plan_spec_counts."""
+        a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(self.L.smc_plan_spec_counts(self.ctx, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), "smc_plan_spec_counts")
+        return a.value, b.value, c.value
 
 
 class Plan(object):
     def __init__(self, eng: Engine, handle, n_loci: int):
         self.eng, self.h, self.n_loci = eng, handle, n_loci
+
+    def ok(self) -> bool:
+        """After the rows have been waited for: are they this batch's (always, for a plan made the exact way)?  smc_plan_spec_ok."""
+        v = ctypes.c_int(1)
+        _lib.check(self.eng.L.smc_plan_spec_ok(self.h, ctypes.byref(v)), "smc_plan_spec_ok")
+        return bool(v.value)
 
     def info(self):
         nl, sb = ctypes.c_int32(), ctypes.c_int64()
