@@ -384,11 +384,7 @@ def main():
         torch.cuda.set_stream(torch.cuda.default_stream(dev))
     # one step at a time (every step on slot 0's stream): what a step takes when nothing of the next one runs beside it
     torch.cuda.synchronize()
-    t_s = time.perf_counter()
-    for _ in range(a.steps):
-        run.step(rows=rows, slot=0)
-    torch.cuda.synchronize()
-    serial_ms = (time.perf_counter() - t_s) / a.steps * 1e3
+    serial_ms = run.serial_ms(a.steps, rows=rows)
     # the same run with the read words in the other width (32 bits), the same way: what the 16-bit word bought on this box
     other_width = None
     if world == 1 and not a.no_other_configs and not os.environ.get("SMC_BENCH_NO_WIDTH_AB"):
@@ -416,9 +412,9 @@ def main():
             "config": {"workload": "%s: %d loci%s x %d reads (%d UMIs x %d rpb), seed %d; as ALIGNMENTS resident in HBM: %s"
                        % (cfg.name, n_loc, "/GPU" if a.scaling == "weak" else " in total", cfg.depth, cfg.n_umi, cfg.rpb, cfg.seed,
                           bench_fa.describe(run, a.config)),
-                       "step": ("smc_build_planes_w16 (sort, count, the walk that writes one 16-bit word per pileup read) -> smc_plan_create_dev -> "
+                       "step": ("smc_build_planes_w16 (sort, count, the walk that writes one 16-bit word per pileup read) -> smc_plan_create_dev_spec -> "
                                 "smc_plan_run_words16 (k_call_v2 + k_filter_loci) -> rows in HBM" if run.word_bits == 16 else
-                                "smc_build_planes (sort, count, the walk that writes one word per pileup read) -> smc_plan_create_dev -> "
+                                "smc_build_planes (sort, count, the walk that writes one word per pileup read) -> smc_plan_create_dev_spec -> "
                                 "smc_plan_run_words (k_call_v2 + k_filter_loci) -> rows in HBM") + ((" -> %s rows gathered to rank 0"
                                % ("packed wire" if packed else "full")) if gather else ""),
                        "loci_total": total_loci, "read_word_bits": run.word_bits,
@@ -438,7 +434,7 @@ def main():
                     "frac": (16.0 * run.reads + 360.0 * run.nl) / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS},
                 # the step one at a time with the read words in the other width, same process, same inputs, right after the headline
                 **({"other_read_word_width_same_run": dict(other_width, ms_per_step_one_at_a_time_this_width=serial_ms)} if other_width else {})}),
-            "step_breakdown": {"slots": a.slots, "ms_per_step_one_at_a_time": serial_ms, "placement": run.placement,
+            "step_breakdown": {"slots": a.slots, "slot_choice": run.slot_choice, "ms_per_step_one_at_a_time": serial_ms, "placement": run.placement,
                                # what the library's write-pattern probe saw when it chose the blocks of the read words (one per slot)
                                "allocation": {"chosen_by": "smc_mem_alloc_best (engine.DevBuf(walk_output=True))", "tries": eng.alloc_tries,
                                               "blocks": list(eng.alloc_log)},

@@ -43,6 +43,7 @@ class AlignmentRun(object):
         allocations (behind spacer allocations of different sizes: allocations made back to back tend to be alike), times the walk
         into each - set-up, outside every timed region - and keeps the fastest."""
         self.eng, self.params = eng, params
+        eng.reset_plan_hint()                    # (a run of its own kind: its first plan is made the exact way, the others are sized from it)
         if shard:
             cfg = dataclasses.replace(cfg, seed=cfg.seed + 7919 * shard, start_pos=cfg.start_pos + n_loci * shard)
         self.cfg = cfg
@@ -97,6 +98,9 @@ class AlignmentRun(object):
                     S["words"].free()
                     S["words"] = self._words_buf()
                 self.words = self.slots[0]["words"]
+        self.slot_choice = None
+        if len(self.slots) > 1 and not os.environ.get("SMC_FA_NO_SLOT_CHOICE"):
+            self._choose_slots()
         if place > 0:
             try:
                 self._place(place)
@@ -104,6 +108,28 @@ class AlignmentRun(object):
                 self.placement = {"note": "placement trials abandoned: %s" % e}
                 eng.trim()
             self.words = self.slots[0]["words"]
+
+    def _choose_slots(self, steps: int = 10):
+        """Two steps in flight on two streams, or one after the other on one?  The second stream lets the builder of step i + 1 run
+        beside the locus kernels of step i: 2-3 % on most boxes, minus 3-5 % on some (measured round 6 on four boxes: 2.56 vs 2.62,
+        2.62 vs 2.76, 2.65 vs 2.73 - and 2.80 vs 2.66 ms per C3 step).  A pipeline picks its depth where it runs: a few steps of each
+        at set-up, outside every timed region; the faster stays."""
+        L, eng = self.eng.L, self.eng
+        ms = {}
+        for n in (1, len(self.slots)):                  # (one slot first: the pools of plan blocks are warm by the time two are timed)
+            self.active_slots = n
+            for _ in range(4):
+                self.step()
+            L.smc_device_sync(eng.ctx)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step()
+            L.smc_device_sync(eng.ctx)
+            ms[n] = (time.perf_counter() - t0) / steps * 1e3
+        self.active_slots = min(ms, key=ms.get)
+        self.slot_choice = {"ms_per_step_by_slots_in_flight": {str(k): round(v, 4) for k, v in ms.items()}, "kept": self.active_slots}
+        for k in self.t:
+            self.t[k] = 0
 
     def _words_buf(self):
         from smcounter_amd.engine import DevBuf
@@ -208,7 +234,9 @@ class AlignmentRun(object):
         # again only when its previous step is through; without that the host runs hundreds of steps ahead, the two streams' queues
         # interleave as they like and the pool of plan blocks is exhausted - measured: X3 0.73 -> 2.3 ms per step)
         if st is not None and self.pace:
-            if len(S.setdefault("done", [])) >= 2:          # (two steps of a slot may be in flight: the one running and the one queued behind it)
+            # (steps in flight: two - one per slot with two slots, the one running and the one queued behind it with one.  Measured
+            # with two per slot on two slots: C3 3.5 ms, X3 2.4 ms per step)
+            while len(S.setdefault("done", [])) >= (1 if self.active_slots > 1 else 2):
                 S["done"].pop(0).synchronize()
         sp = ctypes.c_void_p(st.cuda_stream if st is not None else 0)
         words, uaux, d_loci = S["words"], S["uaux"], S["d_loci"]
@@ -245,6 +273,21 @@ class AlignmentRun(object):
         if keep_plan:
             return plan
         plan.close()
+
+    def serial_ms(self, steps: int, rows=None) -> float:
+        """ms per step with every step on slot 0's stream, one after the other (the host still a step ahead)."""
+        L, eng = self.eng.L, self.eng
+        keep = self.active_slots
+        self.active_slots = 1
+        try:
+            L.smc_device_sync(eng.ctx)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step(rows=rows, slot=0)
+            L.smc_device_sync(eng.ctx)
+            return (time.perf_counter() - t0) / steps * 1e3
+        finally:
+            self.active_slots = keep
 
     def measure_other_word_width(self, steps: int, rows=None):
         """The same run, one step at a time on slot 0, with the read words in the OTHER width (32 bits where the run uses 16): the
@@ -402,12 +445,7 @@ def run_leg(eng, cfg_name: str, n_loci: int, steps: int, warmup: int, blocks: in
     _lib.check(L.smc_build_kernel_ms(eng.ctx, ctypes.byref(k_ms), ctypes.byref(k_n)), "smc_build_kernel_ms")
     L.smc_build_set_timing(eng.ctx, 0)
     # one step at a time (every step on slot 0's stream): what a step takes when nothing of the next one runs beside it
-    L.smc_device_sync(eng.ctx)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        run.step(slot=0)
-    L.smc_device_sync(eng.ctx)
-    serial = (time.perf_counter() - t0) / steps * 1e3
+    serial = run.serial_ms(steps)
     # the locus kernels of the same planes, timed alone with the last plan
     plan = run.step(keep_plan=True, slot=0)
     L.smc_device_sync(eng.ctx)
@@ -420,11 +458,11 @@ def run_leg(eng, cfg_name: str, n_loci: int, steps: int, warmup: int, blocks: in
     n = max(1, run.t["n"])
     out = {
         "workload": describe(run, cfg_name),
-        "step": "smc_build_planes%s (read words) -> smc_plan_create_dev (binning on the device) -> smc_plan_run_words%s -> rows in HBM" % (
+        "step": "smc_build_planes%s (read words) -> smc_plan_create_dev_spec (binning on the device, nothing waits for it) -> smc_plan_run_words%s -> rows in HBM" % (
             ("_w16", "16") if run.word_bits == 16 else ("", "")), "read_word_bits": run.word_bits,
         "value": run.nl * steps / el, "unit": "loci/s", "ms_per_step": el / steps * 1e3,
         "blocks_ms_per_step": [round(t / steps * 1e3, 3) for t in times],
-        "slots": slots, "ms_per_step_one_at_a_time": serial, "placement": run.placement,
+        "slots": slots, "slot_choice": run.slot_choice, "ms_per_step_one_at_a_time": serial, "placement": run.placement,
         "pileup_reads_per_s": run.reads * steps / el,
         "host_ms_per_step": {k: round(v / n * 1e3, 3) for k, v in run.t.items() if k != "n"},
         "k_bp_emit2_ms": k_ms.value, "k_call_v2_ms": c_ms,

@@ -358,6 +358,9 @@ int smc_plan_spec_ok(smc_plan* plan, int* ok);
 /* Plans made by smc_plan_create_dev_spec in this context, how many of them went the exact way, how many the device found not to
  * fit (reads a counter on the device: synchronises it) - for a caller that destroys its plans unchecked (a benchmark loop). */
 int smc_plan_spec_counts(smc_ctx* ctx, int64_t* made, int64_t* exact, int64_t* not_fitting);
+/* Forget what the context's next such plan would be sized from (it then goes the exact way): for a caller that knows its next batch
+ * is of another kind than the last one. */
+int smc_plan_hint_reset(smc_ctx* ctx);
 /* number of kernel launches one smc_plan_run issues, and bytes of device scratch it holds */
 int smc_plan_info(const smc_plan* plan, int32_t* n_launches, int64_t* scratch_bytes);
 

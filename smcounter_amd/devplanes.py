@@ -266,6 +266,7 @@ def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], par
                 for b in [words] + uaux + [p for p in planes if p is not None]:
                     b.free()
                 eng.word_bits = 32
+                eng.drop_spare_tuned()           # (the block chosen for the 16-bit words is of a size nothing asks for again: back to the runtime)
                 i = first
                 continue
             lc_all = LC[0] if len(LC) == 1 else np.concatenate(LC)

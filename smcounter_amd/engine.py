@@ -62,8 +62,8 @@ class DevBuf(object):
         return out
 
     def view(self, offset_bytes: int):
-        """A pointer into the allocation (no ownership)."""
-        return _DevView(self.ptr + offset_bytes)
+        """A pointer into the allocation (no ownership); an array of read words keeps its width."""
+        return _DevView(self.ptr + offset_bytes, self.word_bits)
 
     def free(self):
         if self.ptr and self.eng.ctx:
@@ -88,8 +88,9 @@ def _size_class(n: int) -> int:
 
 
 class _DevView(object):
-    def __init__(self, ptr):
+    def __init__(self, ptr, word_bits: int = 32):
         self.ptr = ptr
+        self.word_bits = word_bits       # (Plan.run_words picks the kernels by it: a view must not lose it - ADVICE r5)
 
     def data_ptr(self) -> int:
         return self.ptr
@@ -141,6 +142,15 @@ class Engine(object):
                 for p in ptrs:
                     self.L.smc_mem_free(self.ctx, p)
         self._spare = {}
+        self._spare_tuned = {}
+
+    def drop_spare_tuned(self):
+        """Give the spare blocks that the write-pattern probe chose (DevBuf(walk_output=True)) back to the runtime: a file that has
+        fallen back to 32-bit read words never asks for the 16-bit block's size again."""
+        if self.ctx:
+            for ptrs in self._spare_tuned.values():
+                for p in ptrs:
+                    self.L.smc_mem_free(self.ctx, p)
         self._spare_tuned = {}
 
     def close(self):
@@ -197,6 +207,10 @@ class Engine(object):
                        "smc_plan_create_dev")
         return Plan(self, h, int(n_loci))
 
+    def reset_plan_hint(self):
+        """The next plan made with `spec_params` goes the exact way (smc_plan_hint_reset): before batches of another kind."""
+        _lib.check(self.L.smc_plan_hint_reset(self.ctx), "smc_plan_hint_reset")
+
     def spec_counts(self):
         """(plans made without the host, of those made the exact way, found not to fit on the device) - smc_plan_spec_counts."""
         a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
@@ -242,6 +256,10 @@ class Plan(object):
         if rows is None:
             rows = self.alloc_rows()
         cp = abi.c_params(params)
+        # (the width travels WITH the array - DevBuf / its views / bench wrappers carry `word_bits`; a torch tensor of 32-bit words has
+        # none.  A wrapper of 16-bit words that dropped it would run the 32-bit kernels on them: anything that is not a tensor must say)
+        if not hasattr(words, "word_bits") and not hasattr(words, "dtype"):
+            raise _lib.SmcError("Plan.run_words: %r does not say how wide its read words are (word_bits)" % type(words).__name__)
         if getattr(words, "word_bits", 32) == 16:                     # (smc_read_word16: what smc_build_planes_w16 has written)
             _lib.check(self.eng.L.smc_plan_run_words16(self.h, ctypes.byref(cp), words.data_ptr(), umi_start.data_ptr(), rows.data_ptr(),
                                                        self._stream_ptr(stream)), "smc_plan_run_words16")

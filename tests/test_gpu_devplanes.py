@@ -481,3 +481,67 @@ def test_long_and_odd_cigars(engine0, tmp_path):
     (_, hb), (_, rb) = host[0], dev[0]
     assert rb.n_device_runs >= 1 and rb.n_host_runs == 0
     _same_batch(rb, hb)
+
+
+def test_plans_made_without_the_host_fit_or_say_so(engine0):
+    """smc_plan_create_dev_spec (ABI 8): the launches of a plan sized from the context's LAST plan instead of this batch's own record -
+    nothing waits for the device.  The first plan of a context goes the exact way; a batch of the same kind (the same, or twice as
+    many loci) fits and gives the exact plan's row bytes; a batch that does not fit (deeper loci: another workgroup class) launches
+    nothing, `ok()` says so, the device's counter counts it, and the plan made again goes the exact way and gives the rows."""
+    import torch
+    from smcounter_amd import devplanes, synth
+    from smcounter_amd.engine import Engine
+    eng = Engine(0)                                              # (a context of its own: the hints are the context's)
+    try:
+        def batch(name, lo, n):
+            cfg = synth.CONFIGS[name]
+            P = synth.params_for(cfg)
+            db = synth.generate_native(cfg, lo, lo + n, P)
+            raw = eng.upload(db)
+            ph = eng.make_plan(db.loci)
+            want = ph.download(ph.run(raw, P)).tobytes()
+            words = ph.pack_words(raw[0], raw[2], torch.empty_like(raw[0]))      # (such a plan runs read words)
+            torch.cuda.synchronize()
+            ph.close()
+            return db, P, [words, raw[4]], devplanes.DevLoci(eng, db.loci), want
+
+        def run_spec(b):
+            db, P, planes, d_loci, want = b
+            plan = eng.make_plan_dev(d_loci, len(db.loci), spec_params=P)
+            rows = plan.run(planes, P)
+            torch.cuda.synchronize()
+            ok = plan.ok()
+            got = plan.download(rows).tobytes()
+            plan.close()
+            return ok, got == want
+
+        a1, a2, a3 = batch("C2", 0, 1500), batch("C2", 1500, 1500), batch("C2", 3000, 3000)
+        assert run_spec(a1) == (True, True)                      # the context's first: made the exact way
+        assert eng.spec_counts() == (0, 1, 0)
+        assert run_spec(a2) == (True, True)                      # sized from a1's record
+        assert run_spec(a3) == (True, True)                      # ... scaled to twice the loci
+        assert run_spec(a1) == (True, True)
+        assert eng.spec_counts() == (3, 1, 0)
+        deep = batch("C5", 0, 300)                               # 8,000 reads per locus: workgroups of 128 threads - no such launch was sized
+        ok, same = run_spec(deep)
+        assert ok is False
+        assert eng.spec_counts() == (4, 1, 1)
+        assert run_spec(deep) == (True, True)                    # made again: the exact way
+        assert eng.spec_counts() == (4, 2, 1)
+        assert run_spec(deep) == (True, True) and run_spec(a2)[0] is False   # (the sizes follow the data: now C2's loci do not fit C5's launches)
+        assert run_spec(a2) == (True, True)                                     # (made again: exact)
+        with pytest.raises(Exception, match="raw-field planes"):                # (and such a plan says so when handed raw-field planes)
+            db, P, planes, d_loci, want = a1
+            raw = eng.upload(db)
+            plan = eng.make_plan_dev(d_loci, len(db.loci), spec_params=P)
+            try:
+                plan.run(raw, P)
+            finally:
+                plan.close()
+        eng.reset_plan_hint()                                                   # (told that another kind of batch follows: no misfit)
+        assert run_spec(deep) == (True, True)
+        assert eng.spec_counts()[2] == 2
+        for b in (a1, a2, a3, deep):
+            b[3].free()
+    finally:
+        eng.close()

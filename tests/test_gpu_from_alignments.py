@@ -255,6 +255,18 @@ def test_a_run_without_room_in_16_bit_words_is_built_with_32(engine0):
     A = synth.generate_alignments(cfg, 300, P, p_del_aln=0.05, p_ins_aln=0.0, p_clip=0.0)
     rb, got = _with_word_bits(engine0, 16, lambda: _gpu_rows(engine0, A, P))
     assert rb.words.word_bits == 16
+    # (b) a quality of exactly 63 - the largest the 16-bit word holds - is NOT "beyond 63" (the walk's byte-lane test
+    # looked at quality + 1 and sent every file with a Q63 to the 32-bit words; the exact path and the host's words16_from_32 took it)
+    a = A["aln"][len(A["aln"]) // 3]
+    A["bq"][2 * (int(a["seq_off"]) + int(a["l_seq"]) // 2) + 1] = 63
+    rb, got = _with_word_bits(engine0, 16, lambda: _gpu_rows(engine0, A, P))
+    assert rb.words.word_bits == 16
+    want, fragile, pi_all, n_al = oracle_rows(A, P, 300, cores)
+    assert abi.compare_rows(got, want, PI_TOL, P_TOL, fragile, pi_all) == []
+    # ... and 64 is
+    A["bq"][2 * (int(a["seq_off"]) + int(a["l_seq"]) // 2) + 1] = 64
+    rb, got = _with_word_bits(engine0, 16, lambda: _gpu_rows(engine0, A, P))
+    assert rb.words.word_bits == 32
 
 
 def test_filter_tallies_by_their_own_kernel_give_the_same_rows(engine0, monkeypatch):
