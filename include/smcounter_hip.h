@@ -361,6 +361,25 @@ int smc_plan_spec_counts(smc_ctx* ctx, int64_t* made, int64_t* exact, int64_t* n
 /* Forget what the context's next such plan would be sized from (it then goes the exact way): for a caller that knows its next batch
  * is of another kind than the last one. */
 int smc_plan_hint_reset(smc_ctx* ctx);
+
+/* (ABI 8) The NON-parity down-sampling of loci over the barcode cap, on the device.  smCounter.py:496-498 seeds Python 2's
+ * Mersenne twister with the position STRING and samples bcDict's keys in Python 2's dict order; the parity path reproduces that on
+ * the host from the barcode texts and marks the dropped keys in umi_start (SMC_LF_SAMPLED / SMC_USTART_DROPPED above).  This call
+ * leaves the same kind of marks without the host's sampler: every key of bcDict of a locus with n_umi > ds (and no marks yet) gets
+ * the 64-bit value made of words 0 and 1 of Philox4x32-10(counter = (identity lo, identity hi, 0, 0), key = the two halves of
+ * (position ^ seed)); the ds smallest stay (ties: the lower index).  `d_ident`: one 64-bit identity per umi_start entry (read
+ * only at loci over the cap) - e.g. a hash of the barcode's text: the sample then depends on (seed, position, barcode) alone, not on
+ * how the caller numbered the barcodes or cut the file into batches; NULL: the barcode's index in its locus.  With
+ * `d_ident_index` (one uint32 per umi_start entry: what smc_build_planes leaves in u_gid at such loci - the run-wide barcode id)
+ * `d_ident` is a table by that index instead.  Counter-based - no
+ * state, no order - so the marks do not depend on the launch; oracle/smc_oracle.c restates it (smc_oracle_philox_marks).  NOT what
+ * the reference samples: rows of such loci carry SMC_ST_DOWNSAMPLED and differ from smCounter's.  d_pos[l]: the 1-based position
+ * of locus l; d_status: a word the call ORs bits into - 1: a locus with more than 2^18 barcodes was left to the stand-in (the ds
+ * lowest indices).  Enqueued on `stream` after whatever wrote the words, before the batch's plan runs. */
+int smc_philox_marks(smc_ctx* ctx, const smc_params* prm, smc_locus* d_loci, int64_t n_loci, const int64_t* d_pos, const void* d_words,
+                     int word_bits, uint32_t* d_umi_start, const uint64_t* d_ident, const uint32_t* d_ident_index, uint64_t seed,
+                     uint32_t* d_status, void* stream);
+void smc_philox4x32_10_host(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 /* number of kernel launches one smc_plan_run issues, and bytes of device scratch it holds */
 int smc_plan_info(const smc_plan* plan, int32_t* n_launches, int64_t* scratch_bytes);
 

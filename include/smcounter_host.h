@@ -74,6 +74,8 @@ int64_t smc_bam_alignments(void* h, const char* chrom, int64_t start0, int64_t e
                            int32_t* n_bc, int32_t* n_pair, int32_t* status);
 int smc_bam_allele_key(void* h, int64_t aln_index, int32_t qpos, int32_t indel, char* out, int cap);
 const char* smc_bam_barcode_name(void* h, int32_t gid);
+/* FNV-1a (64 bits) of the text of every run-wide barcode id of the last smc_bam_alignments: the identities smc_philox_marks keys on. */
+int64_t smc_bam_barcode_idents(void* h, uint64_t* out, int64_t cap);
 
 /* ---------------------------------------------------------------- libsmc_rowfmt.so */
 

@@ -56,6 +56,30 @@ def call_batch(db, cparams, row_dtype, return_fragile=False, return_pi_all=False
     return out if len(out) > 1 else rows
 
 
+def philox(ctr, key):
+    """Philox4x32-10 as oracle/smc_oracle.c restates it (known-answer tests)."""
+    L = lib()
+    c, k, o = np.array(ctr, np.uint32), np.array(key, np.uint32), np.zeros(4, np.uint32)
+    L.smc_oracle_philox(c.ctypes.data_as(ctypes.c_void_p), k.ctypes.data_as(ctypes.c_void_p), o.ctypes.data_as(ctypes.c_void_p))
+    return [int(x) for x in o]
+
+
+def philox_marks(db, cparams, pos, seed=0, ident=None):
+    """The non-parity down-sampling of loci over the barcode cap (include/smcounter_hip.h: smc_philox_marks) on a DeviceBatch:
+    -> (loci with SMC_LF_SAMPLED set where it was applied, umi_start with the dropped keys marked) - copies."""
+    L = lib()
+    loci = np.ascontiguousarray(db.loci).copy()
+    us = np.ascontiguousarray(db.umi_start).copy()
+    pos = np.ascontiguousarray(pos, np.int64)
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rc = L.smc_oracle_philox_marks(ctypes.byref(cparams), ptr(loci), ctypes.c_int64(len(loci)), ptr(pos), ptr(np.ascontiguousarray(db.meta)),
+                                   ptr(np.ascontiguousarray(db.umi)), ptr(us),
+                                   ptr(np.ascontiguousarray(ident, np.uint64)) if ident is not None else None, ctypes.c_uint64(seed))
+    if rc != 0:
+        raise RuntimeError("smc_oracle_philox_marks failed: %d" % rc)
+    return loci, us
+
+
 def call_batch_mt(db, cparams, row_dtype, n_threads, return_fragile=False, return_pi_all=False):
     """The same C restatement over contiguous locus ranges on n_threads host threads (ctypes releases the
     GIL during the call; the library keeps no state).  Used by bench.py for the all-cores C baseline and by the

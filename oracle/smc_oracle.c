@@ -412,6 +412,68 @@ int smc_oracle_call_batch_ex(const smc_params* P, const smc_locus* loci, int64_t
 }
 
 /* exposed for tests: the Fisher restatement against captured scipy calls */
+/* ---- the NON-parity down-sampling of loci over the barcode cap (include/smcounter_hip.h: smc_philox_marks), restated: not the
+ * reference's random.sample (smCounter.py:496-498 - that one is smcounter_amd/py2compat.py's, from barcode texts) but the documented
+ * alternative: a key of bcDict (a barcode with an included read, :467-468) gets the 64-bit value words 0, 1 of
+ * Philox4x32-10(counter = (the barcode's identity - the caller's 64-bit value, or its index -, 0, 0), key = the halves of
+ * (position ^ seed)); the ds smallest stay, ties by index.
+ * Written from the published algorithm (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11; the known answers of
+ * Random123's kat_vectors are in tests/test_oracle_golden.py), independently of csrc/k_philox_marks.inc. */
+static void oracle_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]}, k[2] = {key[0], key[1]};
+    for (int round = 0; round < 10; ++round) {
+        if (round) { k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u; }          /* the Weyl sequence of the key schedule */
+        uint64_t m0 = (uint64_t)0xD2511F53u * c[0], m1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t hi0 = (uint32_t)(m0 >> 32), lo0 = (uint32_t)m0, hi1 = (uint32_t)(m1 >> 32), lo1 = (uint32_t)m1;
+        uint32_t n[4] = {hi1 ^ c[1] ^ k[0], lo1, hi0 ^ c[3] ^ k[1], lo0};
+        memcpy(c, n, sizeof c);
+    }
+    memcpy(out, c, sizeof c);
+}
+void smc_oracle_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { oracle_philox(ctr, key, out); }
+typedef struct { uint64_t r; uint32_t u; } phx_key;
+static int cmp_phx(const void* a, const void* b) {
+    const phx_key *x = (const phx_key*)a, *y = (const phx_key*)b;
+    if (x->r != y->r) return x->r < y->r ? -1 : 1;
+    return x->u < y->u ? -1 : x->u > y->u;
+}
+/* marks umi_start / loci[].flags in place, as the host's reference-exact sampling does; meta / umi: the raw-field planes */
+int smc_oracle_philox_marks(const smc_params* P, smc_locus* loci, int64_t n_loci, const int64_t* pos, const uint32_t* meta,
+                            const uint32_t* umi, uint32_t* umi_start, const uint64_t* ident /* per umi_start entry, or NULL: the index */,
+                            uint64_t seed) {
+    for (int64_t l = 0; l < n_loci; ++l) {
+        smc_locus* L = &loci[l];
+        const int nU = L->n_umi, n = L->n_reads;
+        if (P->ds <= 0 || nU <= P->ds || (L->flags & SMC_LF_SAMPLED)) continue;
+        const uint32_t* m = meta + 4ll * L->read_off4;
+        const uint32_t* um = umi + 4ll * L->read_off4;
+        uint32_t* us = umi_start + L->umi_off;
+        unsigned char* in_bc = (unsigned char*)calloc((size_t)nU + 1, 1);
+        for (int i = 0; i < n; ++i) {                                    /* incCond, smCounter.py:378 (an in-deletion read counts with minBQ, :418) */
+            int bq = (m[i] >> 8) & 0xff, fl = (m[i] >> 16) & 0xff, mq = m[i] >> 24;
+            if (((fl >> SMC_KIND_SHIFT) & 3) == SMC_KIND_GAP) bq = P->min_bq;
+            if (bq >= P->min_bq && mq >= P->min_mq && (fl & SMC_FL_MMOK) && um[i] < (uint32_t)nU) in_bc[um[i]] = 1;
+        }
+        phx_key* keys = (phx_key*)malloc(sizeof(phx_key) * ((size_t)nU + 1));
+        int nk = 0;
+        const uint64_t kx = (uint64_t)pos[l] ^ seed;
+        const uint32_t key[2] = {(uint32_t)kx, (uint32_t)(kx >> 32)};
+        for (int u = 0; u < nU; ++u) {
+            if (!in_bc[u]) continue;
+            const uint64_t id = ident ? ident[L->umi_off + (uint32_t)u] : (uint64_t)(uint32_t)u;
+            const uint32_t ctr[4] = {(uint32_t)id, (uint32_t)(id >> 32), 0u, 0u};
+            uint32_t x[4];
+            oracle_philox(ctr, key, x);
+            keys[nk].r = (uint64_t)x[0] << 32 | x[1]; keys[nk].u = (uint32_t)u; ++nk;
+        }
+        qsort(keys, (size_t)nk, sizeof(phx_key), cmp_phx);
+        for (int k = P->ds; k < nk; ++k) us[keys[k].u] |= SMC_USTART_DROPPED;
+        L->flags |= SMC_LF_SAMPLED;
+        free(keys); free(in_bc);
+    }
+    return 0;
+}
+
 void smc_oracle_fisher(int64_t a, int64_t b, int64_t c, int64_t d, double* oddsratio, double* pvalue) {
     fisher_exact(a, b, c, d, oddsratio, pvalue);
 }

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SMC_HIP_LIB") or os.path.join(HERE, "libsmcounter_hip.so")   # (SMC_HIP_LIB: another build of the same ABI - same-box A/B runs)
 
 SYMBOLS = ("smc_abi_version", "smc_last_error", "smc_row_size", "smc_locus_size", "smc_device_count",
-           "smc_create", "smc_destroy", "smc_plan_create", "smc_plan_create_dev", "smc_plan_create_dev_spec", "smc_plan_spec_ok", "smc_plan_spec_counts", "smc_plan_hint_reset", "smc_plan_destroy", "smc_plan_info",
+           "smc_create", "smc_destroy", "smc_plan_create", "smc_plan_create_dev", "smc_plan_create_dev_spec", "smc_plan_spec_ok", "smc_plan_spec_counts", "smc_plan_hint_reset", "smc_philox_marks", "smc_philox4x32_10_host", "smc_plan_destroy", "smc_plan_info",
            "smc_plan_run", "smc_plan_run_words", "smc_plan_run_words16", "smc_pack_words", "smc_plan_set_timing", "smc_plan_kernel_ms", "smc_call_batch_host", "smc_event_create", "smc_event_record",
            "smc_event_elapsed_ms", "smc_event_destroy", "smc_class_table", "smc_wire_row_size", "smc_pack_rows", "smc_unpack_rows",
            "smc_build_planes", "smc_build_planes_w16", "smc_build_max_depth", "smc_build_set_timing", "smc_build_kernel_ms", "smc_mem_alloc", "smc_mem_alloc_best", "smc_mem_write_probe", "smc_mem_free", "smc_mem_h2d", "smc_mem_d2h",
@@ -64,6 +64,9 @@ def load(with_torch: bool = True):
     L.smc_plan_spec_ok.argtypes = [vp, ctypes.POINTER(ctypes.c_int)]
     L.smc_plan_spec_counts.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i64)]
     L.smc_plan_hint_reset.argtypes = [vp]
+    L.smc_philox_marks.argtypes = [vp, ctypes.POINTER(abi.SmcParams), vp, i64, vp, vp, ctypes.c_int, vp, vp, vp, ctypes.c_uint64, vp, vp]
+    L.smc_philox4x32_10_host.argtypes = [vp, vp, vp]
+    L.smc_philox4x32_10_host.restype = None
     L.smc_plan_destroy.argtypes = [vp]
     L.smc_plan_destroy.restype = None
     L.smc_plan_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i64)]

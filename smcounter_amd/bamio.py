@@ -564,6 +564,8 @@ def _native_lib():
         lib.smc_bam_allele_key.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_char_p, C.c_int]
         lib.smc_bam_barcode_name.argtypes = [C.c_void_p, C.c_int32]
         lib.smc_bam_barcode_name.restype = C.c_char_p
+        lib.smc_bam_barcode_idents.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        lib.smc_bam_barcode_idents.restype = C.c_int64
         lib.smc_bam_span_bytes.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int64]
         lib.smc_bam_span_bytes.restype = C.c_int64
         _NATIVE = lib
@@ -674,6 +676,12 @@ class NativeBam(object):
 
     def barcode_name(self, gid: int) -> str:
         return self._lib.smc_bam_barcode_name(self._h, int(gid)).decode()
+
+    def barcode_idents(self, n_bc: int) -> np.ndarray:
+        """FNV-1a (64 bits) of every barcode text of the last run, by run-wide id: what the non-parity sampler keys on."""
+        out = np.zeros(max(1, int(n_bc)), np.uint64)
+        n = self._lib.smc_bam_barcode_idents(self._h, out.ctypes.data, len(out))
+        return out[:min(int(n), len(out))]
 
     def planes_run(self, chrom: str, lo: int, hi: int, max_reads: int, params, refseq: str, nthreads: int, fasta,
                    arena=None, arena_off: int = 0):

@@ -51,6 +51,13 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--device", type=int, default=0, help="GPU index (single process only: under torch.distributed.run "
                                                           "every rank uses GPU LOCAL_RANK and this flag is ignored)")
     p.add_argument("--batchReads", type=int, default=4_000_000, help="pileup reads per device batch")
+    p.add_argument("--sampler", choices=("reference", "philox"), default="reference",
+                   help="how a locus with more UMIs than the cap (maxMT, or 2 x mtDepth) is down-sampled.  reference (default): as "
+                        "smCounter.py:496-498 does - Python 2's random.sample over the barcode texts, seeded with the position string, "
+                        "reproduced on the host (the same rows as smCounter).  philox: on the GPU, a counter-based generator "
+                        "(Philox4x32-10) keyed by position and --samplerSeed - NOT the reference's sample: the rows of such loci differ "
+                        "from smCounter's (another random subset of the same size); the same for every run, launch shape and GPU count")
+    p.add_argument("--samplerSeed", type=int, default=0, help="seed of --sampler philox")
     return p
 
 
@@ -115,7 +122,8 @@ def call_shard(args, params: VcParams, loci, device: int, early=None):
         from . import devplanes
         # (a batch only lives in HBM here - 16 B per read - so it can be eight times the host-built default)
         batches = devplanes.iter_resident_batches(args.bamFile, ref, loci, params, eng, max_reads=32 * args.batchReads,
-                                                  nthreads=nthreads, all_planes=False)
+                                                  nthreads=nthreads, all_planes=False, sampler=getattr(args, "sampler", "reference"),
+                                                  sampler_seed=getattr(args, "samplerSeed", 0))
         # (a batch ahead in a helper thread: decoding and building batch i + 1 overlaps the kernels and the strings of batch i;
         # the two threads use different staging buffers of the engine, device work is ordered by the default stream)
         if not os.environ.get("SMC_NO_PREFETCH"):
@@ -150,7 +158,8 @@ def call_shard_rows(args, params: VcParams, loci, device: int):
                 parts.append(eng.call_batch_host(db, params)); refs += list(db.ref); tables += list(db.alleles)
         else:
             batches = devplanes.iter_resident_batches(args.bamFile, ref, loci, params, eng, max_reads=32 * args.batchReads,
-                                                      nthreads=nthreads, all_planes=False)
+                                                      nthreads=nthreads, all_planes=False, sampler=getattr(args, "sampler", "reference"),
+                                                      sampler_seed=getattr(args, "samplerSeed", 0))
             for _, rb in _prefetch(batches, depth=1):
                 parts.append(vc.vc_resident_rows(rb, params, eng)); refs += list(rb.ref); tables += list(rb.alleles)
     finally:

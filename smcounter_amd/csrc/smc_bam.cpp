@@ -1611,4 +1611,17 @@ const char* smc_bam_barcode_name(void* h, int32_t gid) {
     return (gid >= 0 && (size_t)gid < b.d_bc_names.size()) ? b.d_bc_names[(size_t)gid].c_str() : "";
 }
 
+// a 64-bit identity of every run-wide barcode id of the last smc_bam_alignments - FNV-1a over its text: what the non-parity sampler
+// keys on (smc_philox_marks: the sample of a locus then does not depend on how the file was cut into runs).  -> the number of ids
+int64_t smc_bam_barcode_idents(void* h, uint64_t* out, int64_t cap) {
+    Bam& b = *(Bam*)h;
+    const int64_t n = (int64_t)b.d_bc_names.size();
+    for (int64_t g = 0; g < n && g < cap; ++g) {
+        uint64_t x = 1469598103934665603ull;
+        for (unsigned char c : b.d_bc_names[(size_t)g]) { x ^= c; x *= 1099511628211ull; }
+        out[g] = x;
+    }
+    return n;
+}
+
 }  // extern "C"

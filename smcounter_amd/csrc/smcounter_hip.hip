@@ -60,5 +60,6 @@
 #include "k_filter_loci.inc"   // kernel 2: filterVariants / Fisher exact for the loci on the worklist
 #include "k_pack_rows.inc"     // kernel 3: rows -> 168-byte wire rows for the multi-GPU gather
 #include "k_pack_words.inc"    // kernel 4: raw-field planes -> one word per read (smc_pack_words)
+#include "k_philox_marks.inc" // the non-parity down-sampling of loci over the barcode cap, Philox4x32-10 keyed by position
 #include "k_plan.inc"          // launch plan of a batch whose descriptors are in HBM (classify + fill)
 #include "host_abi.inc"        // the C ABI of include/smcounter_hip.h

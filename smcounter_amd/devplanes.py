@@ -144,7 +144,8 @@ def pack_words_host(meta: np.ndarray, frag: np.ndarray, loci: np.ndarray) -> np.
 
 
 def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], params, eng, max_reads: int = 128_000_000,
-                          nthreads: int = 0, force_host: bool = False, all_planes: bool = True):
+                          nthreads: int = 0, force_host: bool = False, all_planes: bool = True, sampler: str = "reference",
+                          sampler_seed: int = 0):
     """BAM -> `ResidentBatch` chunks: same loci per chunk as bamio.iter_device_batches_native, planes built on the GPU.
     `all_planes=False`: only what the locus kernels read - the read words and umi_start - is built and kept (a fifth of the
     device memory of a batch, a quarter of the builder's stores); the four raw-field planes (for checks) are then None.
@@ -223,7 +224,8 @@ def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], par
                     if T is not None:
                         T["decode"] += time.perf_counter() - t0
                     done = build_run(A, L, eng, cp, params, chrom, lo, fasta, run_ref, [words] + planes, uaux, slots, umi_base, cap, max_depth,
-                                     bam.allele_key, bam.barcode_name)
+                                     bam.allele_key, bam.barcode_name, sampler=sampler, sampler_seed=sampler_seed,
+                                     barcode_idents=bam.barcode_idents)
                     if done == NARROW:
                         narrow = True
                         break
@@ -280,7 +282,7 @@ def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], par
 
 
 def build_run(A, L, eng, cp, params, chrom, lo, fasta, run_ref, planes, uaux, slot_base, umi_base, cap, max_depth,
-              allele_key, barcode_name, stream_sync=True):
+              allele_key, barcode_name, stream_sync=True, sampler: str = "reference", sampler_seed: int = 0, barcode_idents=None):
     """smc_build_planes over one run's alignments `A` (bamio.NativeBam.alignments_run or synth.generate_alignments) into the
     batch's device arrays (`planes`: [words, meta, umi, frag, dist], any of them None).  `allele_key(ai, qpos, indel)` / `barcode_name(gid)` give the texts the host needs (indel allele
     keys, barcode names for the reference's down-sampling)."""
@@ -338,6 +340,21 @@ def build_run(A, L, eng, cp, params, chrom, lo, fasta, run_ref, planes, uaux, sl
             raise PileupError("base quality > 126 at %s:%d-%d" % (chrom, lo + 1, lo + nl))
         return None
     lc = d_loci.download(LOCUS_DTYPE, nl)
+    if sampler == "philox" and params.ds > 0 and bool((lc["n_umi"] > params.ds).any()):
+        # the NON-parity down-sampling of the loci over the barcode cap, on the device (smc_philox_marks: Philox4x32-10 keyed by
+        # position): marks in umi_start + SMC_LF_SAMPLED in the descriptors, where the reference-exact sampling below leaves its own
+        d_pos = DevBuf(eng, 8 * nl + 256).upload(np.arange(lo + 1, lo + 1 + nl, dtype=np.int64))
+        d_st = DevBuf(eng, 256).upload(np.zeros(4, np.uint32))
+        # (what identifies a barcode is a hash of its TEXT, by the run-wide id the builder left in u_gid at these loci: the sample does
+        # not depend on where the runs and batches of the file were cut)
+        idents = barcode_idents(A["n_bc"]) if barcode_idents is not None else \
+            np.array([_fnv64(barcode_name(g)) for g in range(int(A["n_bc"]))], np.uint64)
+        d_id = DevBuf(eng, 8 * max(1, len(idents)) + 256).upload(idents)
+        _lib.check(L.smc_philox_marks(eng.ctx, ctypes.byref(cp), d_loci.data_ptr(), nl, d_pos.data_ptr(), planes[0].data_ptr(),
+                                      16 if w16 else 32, uaux[0].data_ptr(), d_id.data_ptr(), uaux[1].data_ptr(),
+                                      ctypes.c_uint64(int(sampler_seed) & 0xFFFFFFFFFFFFFFFF), d_st.data_ptr(), ctypes.c_void_p(0)), "smc_philox_marks")
+        lc = d_loci.download(LOCUS_DTYPE, nl)
+        d_pos.free(); d_st.free(); d_id.free()
     for b in (d_aln, d_cig, d_bq, d_loc, d_ref, d_loci, d_cnt):
         b.free()                              # (back to the engine's spare list right away, not whenever the collector gets to them)
     # allele tables: the six fixed keys + what the kernel met, in the order it numbered them
@@ -358,7 +375,7 @@ def build_run(A, L, eng, cp, params, chrom, lo, fasta, run_ref, planes, uaux, sl
             tables[l].append(key)
     d_x.free()
     # the reference's down-sampling (smCounter.py:496-498) on loci over the barcode cap: barcode texts by first included read
-    over = np.nonzero(lc["n_umi"] > params.ds)[0] if params.ds > 0 else []
+    over = np.nonzero((lc["n_umi"] > params.ds) & ((lc["flags"] & LF_SAMPLED) == 0))[0] if params.ds > 0 else []
     if len(over):
         from .py2compat import py2_downsample_barcodes
         for l in over.tolist():
@@ -380,6 +397,14 @@ def build_run(A, L, eng, cp, params, chrom, lo, fasta, run_ref, planes, uaux, sl
     return nl, ns, lc, tables
 
 
+def _fnv64(text: str) -> int:
+    """FNV-1a, 64 bits, of a barcode's text (as smc_bam_barcode_idents computes it natively)."""
+    x = 1469598103934665603
+    for c in text.encode():
+        x = ((x ^ c) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return x
+
+
 def synth_allele_key(A):
     """`allele_key` for a run of synth.generate_alignments (what smc_bam_allele_key answers for a decoded run)."""
     def key(ai, qpos, indel):
@@ -395,7 +420,8 @@ def synth_allele_key(A):
     return key
 
 
-def resident_from_alignments(A, eng, params, all_planes: bool = True, chrom: str = None) -> ResidentBatch:
+def resident_from_alignments(A, eng, params, all_planes: bool = True, chrom: str = None, sampler: str = "reference",
+                             sampler_seed: int = 0) -> ResidentBatch:
     """One run of synthetic alignments (synth.generate_alignments) -> a ResidentBatch built by smc_build_planes; raises when
     the device path does not take the run."""
     from . import synth
@@ -412,7 +438,7 @@ def resident_from_alignments(A, eng, params, all_planes: bool = True, chrom: str
         words = DevBuf(eng, (bits // 8) * cap, walk_output=True)
         words.word_bits = bits
         done = build_run(A, L, eng, abi.c_params(params), params, chrom, lo, ref, run_ref, [words] + planes, uaux, 0, 0, cap + nl,
-                         L.smc_build_max_depth(), synth_allele_key(A), lambda gid: "B%d" % gid)
+                         L.smc_build_max_depth(), synth_allele_key(A), lambda gid: "B%d" % gid, sampler=sampler, sampler_seed=sampler_seed)
         if done != NARROW:
             break
         words.free()

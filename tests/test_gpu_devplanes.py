@@ -545,3 +545,86 @@ def test_plans_made_without_the_host_fit_or_say_so(engine0):
             b[3].free()
     finally:
         eng.close()
+
+
+def test_the_non_parity_sampler_on_the_device_equals_its_restatement(engine0):
+    """smc_philox_marks (the Philox4x32-10 down-sampling SURVEY.md a4 allows as a non-parity mode) against oracle/smc_oracle.c's
+    restatement on a batch whose loci are over the barcode cap: the same marks in umi_start, SMC_LF_SAMPLED set, and the rows of the
+    marked batch through the locus kernels equal the oracle's - with the barcode's index as its identity, with identities per
+    barcode entry, and with a table of identities behind an index array (what the plane builder leaves in u_gid)."""
+    import ctypes
+    import dataclasses
+    import torch
+    import oracle_lib
+    from smcounter_amd import _lib, devplanes, synth
+    cfg = synth.SynthConfig("PH", 96, 70, 12, 20260102)
+    P = dataclasses.replace(synth.params_for(cfg), maxMT=30)
+    db = synth.generate_native(cfg, 0, 96, P)
+    cp = abi.c_params(P)
+    pos = np.arange(5000, 5096, dtype=np.int64)
+    rng = np.random.default_rng(3)
+    n_ent = len(db.umi_start)
+    ident_entry = rng.integers(0, 2 ** 63, size=n_ent, dtype=np.uint64)
+    table = rng.integers(0, 2 ** 63, size=500, dtype=np.uint64)
+    index = rng.integers(0, 500, size=n_ent).astype(np.uint32)
+    raw = engine0.upload(db)
+    ph = engine0.make_plan(db.loci)
+    words = ph.pack_words(raw[0], raw[2], torch.empty_like(raw[0]))
+    torch.cuda.synchronize()
+    ph.close()
+    L = engine0.L
+    dev = raw[0].device
+    for ident, idx, want_ident in ((None, None, None), (ident_entry, None, ident_entry), (table, index, table[index])):
+        d_loci = devplanes.DevLoci(engine0, db.loci)
+        us = raw[4].clone()
+        d_pos = torch.from_numpy(pos).to(dev)
+        st = torch.zeros(4, dtype=torch.int32, device=dev)
+        d_id = torch.from_numpy(ident.view(np.int64)).to(dev) if ident is not None else None
+        d_ix = torch.from_numpy(idx.view(np.int32)).to(dev) if idx is not None else None
+        _lib.check(L.smc_philox_marks(engine0.ctx, ctypes.byref(cp), d_loci.data_ptr(), len(db.loci), d_pos.data_ptr(), words.data_ptr(), 32,
+                                      us.data_ptr(), d_id.data_ptr() if d_id is not None else None, d_ix.data_ptr() if d_ix is not None else None,
+                                      ctypes.c_uint64(11), st.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "smc_philox_marks")
+        torch.cuda.synchronize()
+        got_us = us.cpu().numpy().view(np.uint32)
+        got_loci = d_loci.download(features.LOCUS_DTYPE, len(db.loci))
+        want_loci, want_us = oracle_lib.philox_marks(db, cp, pos, seed=11, ident=want_ident)
+        assert int(st[0]) == 0 and np.array_equal(got_us, want_us) and got_loci.tobytes() == want_loci.tobytes()
+        assert (got_loci["flags"] & features.LF_SAMPLED).all() and (got_us >> 31).sum() > 0
+        plan = engine0.make_plan(got_loci)
+        got = plan.download(plan.run([words, us], P))
+        plan.close()
+        want = oracle_lib.call_batch(dataclasses.replace(db, loci=want_loci, umi_start=want_us), cp, abi.ROW_DTYPE)
+        assert abi.compare_rows(got, want) == []
+        assert (got["used_mt"] == P.ds).all() and ((got["status"] & abi.ST_DOWNSAMPLED) != 0).all()
+        d_loci.free()
+
+
+@pytest.mark.parametrize("all_planes", [False, True])
+def test_the_non_parity_sampler_does_not_depend_on_how_the_file_is_cut(engine0, tmp_path, all_planes):
+    """--sampler philox through the BAM path: a barcode's identity is a hash of its TEXT, so the rows of the loci over the barcode
+    cap are the same whether the file is taken as one batch or cut into many runs and batches (where the run-wide barcode ids, the
+    barcodes' numbers at a locus and the launches all differ); they differ from the reference-exact sample's rows, carry
+    SMC_ST_DOWNSAMPLED and usedMT = ds; loci under the cap are untouched by the choice of sampler."""
+    import test_bamio
+    from smcounter_amd import devplanes, vc
+    bam, fa_path, loci = test_bamio._random_bam(tmp_path, 23, True)
+    fa = fasta.FastaFile(fa_path)
+    P = VcParams(mtDepth=4, rpb=3.0, hpLen=8, minBQ=15, minMQ=20, mismatchThr=8.0)       # ds = 8 < the file's 25 barcodes
+
+    def rows_of(max_reads, sampler, seed=0):
+        out = []
+        for _, rb in devplanes.iter_resident_batches(bam, fa, loci, P, engine0, max_reads=max_reads, nthreads=2, all_planes=all_planes,
+                                                     sampler=sampler, sampler_seed=seed):
+            out.append(vc.vc_resident_rows(rb, P, engine0))
+        return np.concatenate(out)
+
+    whole, cut = rows_of(2_000_000, "philox"), rows_of(3000, "philox")
+    assert len(whole) == len(cut) == len(loci)
+    assert whole.tobytes() == cut.tobytes()
+    ref = rows_of(2_000_000, "reference")
+    over = (whole["status"] & abi.ST_DOWNSAMPLED) != 0
+    assert over.any() and np.array_equal(over, (ref["status"] & abi.ST_DOWNSAMPLED) != 0)
+    assert (whole["used_mt"][over] == P.ds).all()
+    assert whole[~over].tobytes() == ref[~over].tobytes()
+    assert whole[over].tobytes() != ref[over].tobytes()                         # (another subset of the same size)
+    assert rows_of(2_000_000, "philox", seed=5)[over].tobytes() != whole[over].tobytes()

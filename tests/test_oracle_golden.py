@@ -103,3 +103,55 @@ def test_calprob_known_answers():
     pb2.frag = np.array([0, 1], np.uint32)
     R = oracle_lib.call_batch(features.extract_features(pb2, P), abi.c_params(P), abi.ROW_DTYPE)
     assert abs(R["pi"][0][0] - 3.3441462052809996) < 1e-9
+
+
+PHILOX_KAT = (  # Random123's known answers for philox4x32-10 (kat_vectors): counter, key -> output
+    ((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+    ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+    ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+)
+
+
+def test_philox_known_answers_and_the_non_parity_sampler():
+    """The optional non-parity down-sampling SURVEY.md a4 allows (smc_philox_marks): the oracle's Philox4x32-10 against the published
+    known answers, and its marks on loci over the barcode cap: exactly ds keys of bcDict stay, the ones with the smallest
+    (Philox(position ^ seed, barcode index), index); another position or seed gives another sample; loci under the cap and loci the
+    host has sampled already are left alone; the rows carry SMC_ST_DOWNSAMPLED and usedMT = ds."""
+    import oracle_lib
+    from smcounter_amd import abi, synth
+    for ctr, key, want in PHILOX_KAT:
+        assert tuple(oracle_lib.philox(ctr, key)) == want
+    cfg = synth.SynthConfig("PH", 40, 60, 8, 20260101)
+    import dataclasses
+    P = dataclasses.replace(synth.params_for(cfg), maxMT=25)
+    assert P.ds == 25
+    db = synth.generate_native(cfg, 0, 40, P)
+    cp = abi.c_params(P)
+    pos = np.arange(1000, 1040, dtype=np.int64)
+    loci, us = oracle_lib.philox_marks(db, cp, pos, seed=7)
+    over = db.loci["n_umi"] > P.ds
+    assert over.all() and (loci["flags"] & 1).all()
+    meta, umi = np.asarray(db.meta), np.asarray(db.umi)
+    for l in range(40):
+        L0 = db.loci[l]
+        o, nu, n, r0 = int(L0["umi_off"]), int(L0["n_umi"]), int(L0["n_reads"]), 4 * int(L0["read_off4"])
+        m = meta[r0:r0 + n]
+        bq, fl, mq = (m >> 8) & 0xff, (m >> 16) & 0xff, m >> 24
+        inc = (bq >= P.minBQ) & (mq >= P.minMQ) & ((fl & 4) != 0)
+        keys = np.unique(umi[r0:r0 + n][inc])
+        dropped = np.nonzero(us[o:o + nu] & 0x80000000)[0]
+        assert set(dropped) <= set(keys.tolist()) and len(keys) - len(dropped) == min(len(keys), P.ds)
+        k = (int(pos[l]) ^ 7)
+        rank = sorted(keys.tolist(), key=lambda u: (tuple(oracle_lib.philox((u, 0, 0, 0), (k & 0xffffffff, k >> 32))[:2]), u))
+        assert set(rank[P.ds:]) == set(dropped.tolist())
+    loci2, us2 = oracle_lib.philox_marks(db, cp, pos, seed=8)
+    loci3, us3 = oracle_lib.philox_marks(db, cp, pos + 1, seed=7)
+    assert (us2 != us).any() and (us3 != us).any()
+    again = oracle_lib.philox_marks(db, cp, pos, seed=7)
+    assert (again[1] == us).all()
+    dbm = dataclasses.replace(db, loci=loci, umi_start=us)
+    rows = oracle_lib.call_batch(dbm, cp, abi.ROW_DTYPE)
+    assert (rows["used_mt"] == P.ds).all() and ((rows["status"] & abi.ST_DOWNSAMPLED) != 0).all()
+    # marks that are already there (the host's reference-exact sample) stay
+    loci4, us4 = oracle_lib.philox_marks(dbm, cp, pos, seed=99)
+    assert (us4 == us).all()
