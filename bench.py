@@ -455,6 +455,7 @@ def main():
             out["cpu_baseline"], out["cpu_baseline_c"] = cpu["python_pool"], cpu["c_port"]
             out["cpu_baseline_c_all_cores"] = cpu["c_port_all_cores"]
             out["cpu_baseline_c_from_alignments"] = cpu["c_from_alignments"]
+            out["cpu_baseline_object_adapter"] = cpu["object_adapter"]
             out["cpu_baseline_single_process"] = cpu["python_single"]
             out["cpu_baseline_pool_chunked"] = cpu["python_pool_chunked"]
         if world == 1 and not a.no_parity:
@@ -698,6 +699,17 @@ def cpu_leg(a):
     got = vc_port.call_shared(shared, params, range(n_py), pool)
     dt_py = time.perf_counter() - t
     vc_port.unshare_batch(shared)
+    # the port fed the way the REFERENCE's worker is fed (SURVEY.md 8d "through an object adapter"): pysam-like objects per pileup read,
+    # the read name split and joined, the tag list walked for NM, the CIGAR walked, string allele keys (oracle/vc_port_objects.py,
+    # smCounter.py:316-479) - every worker maps the run's alignments, makes the objects of its own loci (not timed: the reference's
+    # worker reads them from its BAM) and times its pass; the rate is all loci over the slowest worker's pass
+    import vc_port_objects
+    per_w = 6
+    A_o = synth.generate_alignments(cfg, min(n, cores * per_w), params, nthreads=min(48, cores))
+    ref_o = synth.aln_ref_fetch(int(A_o["start0"]), int(A_o["start0"]) + int(A_o["nl"]) + 256)
+    vc_port_objects.timed_pass(A_o, params, ref_o, min(cores, 8), 1, pool)      # (imports in the workers)
+    n_obj, dt_obj, w_obj, _ = vc_port_objects.timed_pass(A_o, params, ref_o, cores, per_w, pool)
+    del A_o
     vc_port.call_config(a.config, params, range(cores), pool)          # (first import of the generator in every worker)
     n_ch = min(n, 40 * cores)
     t = time.perf_counter()
@@ -718,6 +730,12 @@ def cpu_leg(a):
                                   "multiprocessing.Pool(%d), one task per locus as smCounter.py:683-685, %s, %.1f s (pool already "
                                   "started); ideal_all_cores = the single-process rate x %d physical cores"
                                   % (n_py, cores, "the loci's pileups made BEFORE the clock starts and mapped by the workers", dt_py, phys)},
+        "object_adapter": {"value": n_obj / dt_obj, "unit": "loci/s", "cores": phys, "logical_cpus": cores, "kind": "port",
+                           "per_physical_core": n_obj / dt_obj / phys,
+                           "sample": "first %d loci AS pysam-like objects (oracle/vc_port_objects.py: qname split, NM tag, CIGAR scan, string "
+                                     "allele keys - smCounter.py:316-479 - then the port's :482-600), %d workers x %d loci each, objects made "
+                                     "before each worker's clock starts; rate = loci / the slowest worker's pass (%.2f s)"
+                                     % (n_obj, w_obj, per_w, dt_obj)},
         "python_pool_chunked": {"value": n_ch / dt_ch, "unit": "loci/s", "cores": phys, "logical_cpus": cores, "kind": "port",
                                 "sample": "first %d loci, the same pool with 20 consecutive loci per task, every worker generating its own "
                                           "loci inside the clock (rounds 2-3's variant), %.1f s" % (n_ch, dt_ch)},

@@ -148,6 +148,13 @@ def vc_locus(meta, umi, frag, dist, ref, n_alleles, snp_mask, min_bq, min_mq, mt
             else:
                 del one[s]
                 t[T_DISC] += 1
+    return _finish(tal, bc, all_frags, cvg, ref, snp_mask, mt_drop, ds, smt, dropped)
+
+
+def _finish(tal, bc, all_frags, cvg, ref, snp_mask, mt_drop, ds, smt, dropped=None):
+    """smCounter.py:482-600 on what the scan of a locus left: tallies per allele id, bcDict (barcode -> {fragment: [allele id, error
+    probability, paired]}), allBcDict (barcode -> fragments), coverage.  (Shared by vc_locus - integer planes in - and
+    vc_port_objects.vc_locus_objects - pysam-like objects in.)"""
     row = dict(status=0, cvg=cvg, all_mt=len(all_frags), all_frag=sum(len(v) for v in all_frags.values()),
                dp=[tal[k][T_CNT] for k in range(4)])
     used = min(ds, len(bc))
