@@ -101,6 +101,12 @@ class AlignmentRun(object):
         self.slot_choice = None
         if len(self.slots) > 1 and not os.environ.get("SMC_FA_NO_SLOT_CHOICE"):
             self._choose_slots()
+        # (tests: one rank of a multi-rank bench steps through ONE slot while the others use two - its row buffers are then all filled
+        # by one stream, which the gather has to order against: ADVICE r4)
+        if os.environ.get("SMC_FA_ONE_SLOT_ON_RANK") is not None and os.environ.get("SMC_FA_ONE_SLOT_ON_RANK") == os.environ.get("RANK", "0"):
+            self.active_slots = 1
+        elif os.environ.get("SMC_FA_ONE_SLOT_ON_RANK") is not None and len(self.slots) > 1:
+            self.active_slots = len(self.slots)
         if place > 0:
             try:
                 self._place(place)

@@ -109,3 +109,23 @@ def test_rccl_runs_the_gather_path_with_one_rank():
     assert "gathered to rank 0" in d["config"]["parallelism"]
     assert d["gather_check"] == {"ranks": 1, "blocks_equal_what_was_sent": True, "bytes_per_rank": 20000 * 168}
     assert d["parity"]["loci"] == 20000 and d["parity"]["mismatches"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_two_ranks_on_one_gpu_gather_what_they_sent_when_one_rank_uses_one_slot():
+    """The N > 1 bench path end to end on the one GPU of the test box (SMC_BENCH_SHARE_GPU: both ranks on GPU 0, gloo between them -
+    RCCL refuses two ranks on one device): every step's packed rows gathered to rank 0 through dist.RowPipeline while the next step
+    computes.  Rank 1 is made to step through ONE slot (its two row buffers are then filled by the same stream) while rank 0
+    alternates between two - the configuration in which the gather once raced with the stream that fills the buffer (ADVICE r4);
+    the bench compares what rank 0 received with what every rank sent."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SMC_BENCH_SHARE_GPU="1", SMC_FA_ONE_SLOT_ON_RANK="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--blocks", "2",
+                        "--loci-per-gpu", "12000"], env=env, capture_output=True, text=True, timeout=850)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1 and len(lines[0]) <= 4096
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert d["gather_check"] == {"ranks": 2, "blocks_equal_what_was_sent": True, "bytes_per_rank": 12000 * 168}
