@@ -192,22 +192,7 @@ class AlignmentRun(object):
         # the second slot costs: then every step goes through the first
         if len(kept) > 1 and kept[1] > 1.015 * kept[0]:
             self.active_slots = 1
-        # rows per part of the walk (SMC_BP_PART, the library's knob; its default 256): 192 and 256 are within 2 % of each other and
-        # which one is ahead differs from box to box - a few steps with each, the faster stays
         part_ms = {}
-        if not os.environ.get("SMC_BP_PART"):
-            L = eng.L
-            for part in (192, 256):
-                os.environ["SMC_BP_PART"] = str(part)
-                self.step(slot=0)
-                L.smc_device_sync(eng.ctx)
-                t0 = time.perf_counter()
-                for _ in range(8):
-                    self.step(slot=0)
-                L.smc_device_sync(eng.ctx)
-                part_ms[part] = (time.perf_counter() - t0) / 8 * 1e3
-            best = min(part_ms, key=part_ms.get)
-            os.environ["SMC_BP_PART"] = str(best)
         self.placement = {"walk_ms_by_allocation": [round(x, 3) for x in ms], "kept": [round(x, 3) for x in kept], "slots_used": self.active_slots,
                           "step_ms_by_rows_per_part": {str(k): round(v, 3) for k, v in part_ms.items()},
                           "note": "which allocation holds the read words moves the walk's time (DESIGN.md section 8); candidates are timed "

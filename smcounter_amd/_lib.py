@@ -23,6 +23,13 @@ class SmcError(RuntimeError):
     pass
 
 
+def exp_env(name: str, default=None):
+    """An EXPERIMENT switch of the Python host (measurements, tests): read only when SMC_EXPERIMENTAL is set to anything but 0, as
+    the native libraries read theirs - a stray variable in a production environment changes nothing."""
+    on = os.environ.get("SMC_EXPERIMENTAL", "0") not in ("", "0")
+    return os.environ.get(name, default) if on else default
+
+
 _LIB = None
 
 

@@ -16,7 +16,7 @@ import datetime
 import os
 import sys
 
-from . import bamio, bedops, fasta, postfilter, runlog, vc, writers
+from . import _lib, bamio, bedops, fasta, postfilter, runlog, vc, writers
 from . import dist as smcdist
 from .params import VcParams
 
@@ -94,7 +94,7 @@ def _release_engine(eng):
     """The engine stays with the process: a second main() in the same process finds the context, its tables and its buffers
     again, and the command line does not spend 20 ms of its wall time freeing device memory the exiting process gives back
     anyway (SMC_CLOSE_ENGINE=1: close it, as round 2 did)."""
-    if os.environ.get("SMC_CLOSE_ENGINE"):
+    if _lib.exp_env("SMC_CLOSE_ENGINE"):
         _ENGINES.pop(eng.device, None)
         eng.close()
     else:
@@ -126,7 +126,7 @@ def call_shard(args, params: VcParams, loci, device: int, early=None):
                                                   sampler_seed=getattr(args, "samplerSeed", 0))
         # (a batch ahead in a helper thread: decoding and building batch i + 1 overlaps the kernels and the strings of batch i;
         # the two threads use different staging buffers of the engine, device work is ordered by the default stream)
-        if not os.environ.get("SMC_NO_PREFETCH"):
+        if not _lib.exp_env("SMC_NO_PREFETCH"):
             batches = _prefetch(batches, depth=1)
         for first, rb in batches:
             output.add(vc.vc_resident(rb, params, ref, eng))

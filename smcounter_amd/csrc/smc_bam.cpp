@@ -339,12 +339,19 @@ void parse_body(const uint8_t* p, size_t r_size, Aln& a, int32_t& tid) {
 // libdeflate, when the image has it (the shared object without its header: the three entry points are declared here),
 // inflates a BGZF block 2-3 x faster than zlib; zlib stays the fallback.
 #include <dlfcn.h>
+// (environment switches of the decoder are experiment knobs: read only under SMC_EXPERIMENTAL, as in the HIP library)
+static const char* exp_env(const char* name) {
+    const char* const xv = getenv("SMC_EXPERIMENTAL");
+    const bool on = xv && *xv && strcmp(xv, "0") != 0;                             // (looked at every time: tests switch it on and off)
+    const char* v = getenv(name);
+    return on ? v : nullptr;
+}
 struct Libdeflate {
     void* (*alloc)(void) = nullptr;
     int (*decompress)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;
     void (*release)(void*) = nullptr;
     Libdeflate() {
-        if (getenv("SMC_BAM_ZLIB")) return;
+        if (exp_env("SMC_BAM_ZLIB")) return;
         void* h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
         if (!h) return;
         alloc = (void* (*)(void))dlsym(h, "libdeflate_alloc_decompressor");
@@ -385,7 +392,7 @@ struct BlockStream {
         {
             // (128 KB of compressed bytes per thread and refill: every refill is two rounds of the pool - inflate, record walk -, and
             // at 64 KB the 58,000x run's seven refills cost 2 ms more than its four do)
-            static const int sh = getenv("SMC_BAM_REFILL_SHIFT") ? atoi(getenv("SMC_BAM_REFILL_SHIFT")) : 17;
+            static const int sh = exp_env("SMC_BAM_REFILL_SHIFT") ? atoi(exp_env("SMC_BAM_REFILL_SHIFT")) : 17;
             want = std::min<size_t>(want, std::max<size_t>(1u << 20, (size_t)nthreads << sh));
         }
         want = std::min<size_t>(std::max<size_t>(want, 1u << 18), 256u << 20);
@@ -497,7 +504,7 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, RawVe
             while (w >= 0 && iv[(size_t)w] == 0) --w;
             if (w >= 0) voff = iv[(size_t)w];
         }
-        if (tid == b.cur_tid && !getenv("SMC_BAM_NO_CURSOR")) {
+        if (tid == b.cur_tid && !exp_env("SMC_BAM_NO_CURSOR")) {
             if (b.cur_end >= 0 && start0 >= b.cur_end && b.cur_voff_end > voff) voff = b.cur_voff_end;
             else if (start0 >= b.cur_start && b.cur_voff > voff) voff = b.cur_voff;
         }
@@ -552,7 +559,7 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, RawVe
                 next = o + 4 + (size_t)sz;
                 return true;
             };
-            const int walk_test = getenv("SMC_BAM_WALK_TEST") ? atoi(getenv("SMC_BAM_WALK_TEST")) : 0;
+            const int walk_test = exp_env("SMC_BAM_WALK_TEST") ? atoi(exp_env("SMC_BAM_WALK_TEST")) : 0;
             bool done = false;
             while (!done) {
                 const size_t avail = bs.data.size();
@@ -719,7 +726,7 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, RawVe
         // first records per stretch; a prefix over the stretches gives the ids.  Two different strings with one hash - never seen -
         // send the run to the sharded string-map path below.  Ids in file order are also what the device builder's sort likes: the
         // ids under a tile's window then lie in a narrow range (k_bp_sort_seg narrows its keys to it).
-        bool collided = getenv("SMC_BAM_SHARDS") != nullptr;                    // (tests: the sharded path)
+        bool collided = exp_env("SMC_BAM_SHARDS") != nullptr;                    // (tests: the sharded path)
         const size_t NP = parsed.size();
         const int NCH = (int)std::min<size_t>(256, NP / 2048 + 1);
         std::vector<uint32_t> nf_bc((size_t)NCH + 1, 0), nf_pair((size_t)NCH + 1, 0), n_kept((size_t)NCH + 1, 0);
@@ -817,7 +824,7 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, RawVe
             // colliding hash resolved through a string map.  Sharded by hash over the threads: a shard owns its hashes, so ids are
             // dense and exact whatever the thread count (they number DISTINCT strings, shard by shard).
         while (SH < 64 && SH * 2 <= b.io_threads && (size_t)SH * 2048 < n_keep) SH *= 2;
-        if (const char* e = getenv("SMC_BAM_SHARDS")) { SH = 1; while (SH < 64 && SH * 2 <= atoi(e)) SH *= 2; }   // (tests)
+        if (const char* e = exp_env("SMC_BAM_SHARDS")) { SH = 1; while (SH < 64 && SH * 2 <= atoi(e)) SH *= 2; }   // (tests)
         // the kept records are first binned by shard (stretches of the file in parallel, a bin per stretch and shard; a
         // shard then walks its bins stretch by stretch, i.e. in file order) so that a shard touches only its own records
         const int NB = SH == 1 ? 1 : (int)std::min<size_t>(256, parsed.size() / 2048 + 1);
@@ -959,7 +966,7 @@ int collect_reads(Bam& b, const char* chrom, int64_t start0, int64_t end0, RawVe
         }
         n_bc = bc_off[(size_t)SH]; n_pair = pair_off[(size_t)SH];
         }
-        if (getenv("SMC_BAM_TIMING")) {
+        if (exp_env("SMC_BAM_TIMING")) {
             const auto tc3 = std::chrono::steady_clock::now();
             auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
             fprintf(stderr, "collect_reads: %zu records, %zu kept: inflate + boundaries %.1f ms (read %.1f, inflate %.1f), parse %.1f ms, keep %.1f ms, intern %.1f ms, gather %.1f ms (%zu KB inflated, %d shards; record walk: %d pieces, %d not joined at once)\n",
@@ -1053,7 +1060,7 @@ int smc_bam_open(const char* path, void** out) {
     Bam* b = new Bam();
     b->fh = fopen(path, "rb");
     if (!b->fh) { delete b; return -1; }
-    if (!getenv("SMC_BAM_NO_MMAP")) {
+    if (!exp_env("SMC_BAM_NO_MMAP")) {
         struct stat sb;
         if (fstat(fileno(b->fh), &sb) == 0 && sb.st_size > 0) {
             void* m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fileno(b->fh), 0);
@@ -1409,7 +1416,7 @@ int64_t smc_bam_planes(void* h, const char* chrom, int64_t start0, int64_t end0,
         b.ds_info += t_ds[(size_t)t];
     }
     *n_loci_done = nl; *n_slots = slots; *n_umi_start = (int64_t)b.p_umi_start.size();
-    if (getenv("SMC_BAM_TIMING")) {
+    if (exp_env("SMC_BAM_TIMING")) {
         const auto t_2 = std::chrono::steady_clock::now();
         fprintf(stderr, "smc_bam_planes: %zu alignments, %lld loci, %lld reads: fetch %.1f ms, pileup %.1f ms (%d threads) [prep %.1f, threads %.1f]\n",
                 reads.size(), (long long)nl, (long long)total, std::chrono::duration<double, std::milli>(t_1 - t_0).count(),
@@ -1580,7 +1587,7 @@ int64_t smc_bam_alignments(void* h, const char* chrom, int64_t start0, int64_t e
         });
     }
     *n_loci_done = nl; *n_slots = slots; *n_bc_out = n_bc; *n_pair_out = n_pair; *status = st;
-    if (getenv("SMC_BAM_TIMING")) {
+    if (exp_env("SMC_BAM_TIMING")) {
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         fprintf(stderr, "smc_bam_alignments: %zu alignments, %lld loci, %lld reads: collect %.1f ms, depth + sizes %.1f ms, pack %.1f ms, windows %.1f ms\n",
                 reads.size(), (long long)nl, (long long)total, ms(t_a0, t_a1), ms(t_a1, t_p0), ms(t_p0, t_p1), ms(t_p1, std::chrono::steady_clock::now()));

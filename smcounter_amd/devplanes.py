@@ -191,7 +191,7 @@ def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], par
             nb = bam.span_bytes(chrom, int(pos_all[i]) - 1, int(pos_all[jj]))
             if 0 <= nb < FIRST_RUN_WHOLE_BYTES:
                 span_cap = 65536
-            if os.environ.get("SMC_FIRST_RUN_8192"):                                             # (the switch: measurement)
+            if _lib.exp_env("SMC_FIRST_RUN_8192"):                                             # (the switch: measurement)
                 span_cap = 8192
         j = min(int(stretch_end[i]), i + span_cap - 1)
         return chrom, int(pos_all[i]) - 1, int(pos_all[j]), max_reads - total

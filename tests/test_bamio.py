@@ -10,6 +10,13 @@ from smcounter_amd.params import VcParams
 import oracle_lib
 
 
+@pytest.fixture(autouse=True)
+def _experiment_switches(monkeypatch):
+    """The environment switches these tests flip (chunk geometries, poisoned scratch, forced code paths) are experiment knobs: the
+    libraries read them only under SMC_EXPERIMENTAL."""
+    monkeypatch.setenv("SMC_EXPERIMENTAL", "1")
+
+
 def _naive_columns(recs, pos0):
     """Expand every read base by base (no shortcuts) and report what sits on pos0."""
     out = []

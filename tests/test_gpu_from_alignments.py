@@ -16,6 +16,13 @@ PI_TOL = 1e-6
 P_TOL = 1e-6
 
 
+@pytest.fixture(autouse=True)
+def _experiment_switches(monkeypatch):
+    """The environment switches these tests flip (chunk geometries, poisoned scratch, forced code paths) are experiment knobs: the
+    libraries read them only under SMC_EXPERIMENTAL."""
+    monkeypatch.setenv("SMC_EXPERIMENTAL", "1")
+
+
 def _gpu_rows(engine0, A, P):
     """The product path on one run of alignments: words built on the device, plan made on the device, rows back."""
     from smcounter_amd import devplanes

@@ -16,6 +16,13 @@ PI_TOL = 1e-6
 P_TOL = 1e-6
 
 
+@pytest.fixture(autouse=True)
+def _experiment_switches(monkeypatch):
+    """The environment switches these tests flip (chunk geometries, poisoned scratch, forced code paths) are experiment knobs: the
+    libraries read them only under SMC_EXPERIMENTAL."""
+    monkeypatch.setenv("SMC_EXPERIMENTAL", "1")
+
+
 @pytest.mark.parametrize("path", golden_files(), ids=os.path.basename)
 def test_golden_rows_vs_oracle_and_reference(engine0, path):
     pb, db, P, refp, expected = load_golden(path)
