@@ -143,6 +143,9 @@ def pack_words_host(meta: np.ndarray, frag: np.ndarray, loci: np.ndarray) -> np.
     return np.where(valid, w, np.uint32(0)).astype(np.uint32)
 
 
+READS_PER_BYTE = 6        # pileup reads a batch is sized for per compressed byte of the file under its targets (typical: ~ 2.5)
+
+
 def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], params, eng, max_reads: int = 128_000_000,
                           nthreads: int = 0, force_host: bool = False, all_planes: bool = True, sampler: str = "reference",
                           sampler_seed: int = 0):
@@ -169,6 +172,25 @@ def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], par
             brk |= np.array([chrom_all[k] != chrom_all[k + 1] for k in range(n - 1)], bool)
         ends = np.append(np.flatnonzero(brk), n - 1)
         stretch_end = ends[np.searchsorted(ends, np.arange(n))]
+    # The device arrays of a batch are sized for max_reads - but not for more than the FILE can hold (a 2 MB BAM made every
+    # batch allocate three 576 MB barcode arrays and a read-word block large enough to send the library through its search among
+    # twelve allocations).  The linear index says how many compressed bytes lie under the target stretches; a batch takes at most
+    # READS_PER_BYTE pileup reads per byte of them (a 150-base read is 60-100 compressed bytes and at most 150 pileup reads; an estimate
+    # that is too low only ends batches earlier - the decoder is handed `max_reads - total` and stops there).
+    if n and not _lib.exp_env("SMC_NO_FILE_SIZED_BATCH"):
+        try:
+            nb, seen = 0, set()
+            for e in np.unique(stretch_end).tolist():
+                b = int(np.searchsorted(stretch_end, e, side="left"))
+                k = bam.span_bytes(chrom_all[b], int(pos_all[b]) - 1, int(pos_all[e]))
+                if k < 0:
+                    nb = -1
+                    break
+                nb += int(k)
+            if nb >= 0:
+                max_reads = int(min(max_reads, max(4_000_000, READS_PER_BYTE * nb)))
+        except Exception:
+            pass
     cap = max_reads + (max_reads >> 3) + 65536
     per_locus = 0.0          # pileup reads per locus of the previous run: sizes the next run (a run is decoded as a whole)
 
