@@ -708,6 +708,7 @@ def cpu_leg(a):
     A_o = synth.generate_alignments(cfg, min(n, cores * per_w), params, nthreads=min(48, cores))
     ref_o = synth.aln_ref_fetch(int(A_o["start0"]), int(A_o["start0"]) + int(A_o["nl"]) + 256)
     vc_port_objects.timed_pass(A_o, params, ref_o, min(cores, 8), 1, pool)      # (imports in the workers)
+    n_one_o, dt_one_o, _, _ = vc_port_objects.timed_pass(A_o, params, ref_o, 1, per_w, pool)   # one worker alone: what a core does with it
     n_obj, dt_obj, w_obj, _ = vc_port_objects.timed_pass(A_o, params, ref_o, cores, per_w, pool)
     del A_o
     vc_port.call_config(a.config, params, range(cores), pool)          # (first import of the generator in every worker)
@@ -731,11 +732,11 @@ def cpu_leg(a):
                                   "started); ideal_all_cores = the single-process rate x %d physical cores"
                                   % (n_py, cores, "the loci's pileups made BEFORE the clock starts and mapped by the workers", dt_py, phys)},
         "object_adapter": {"value": n_obj / dt_obj, "unit": "loci/s", "cores": phys, "logical_cpus": cores, "kind": "port",
-                           "per_physical_core": n_obj / dt_obj / phys,
+                           "per_physical_core": n_obj / dt_obj / phys, "one_worker_alone": n_one_o / dt_one_o,
                            "sample": "first %d loci AS pysam-like objects (oracle/vc_port_objects.py: qname split, NM tag, CIGAR scan, string "
                                      "allele keys - smCounter.py:316-479 - then the port's :482-600), %d workers x %d loci each, objects made "
-                                     "before each worker's clock starts; rate = loci / the slowest worker's pass (%.2f s)"
-                                     % (n_obj, w_obj, per_w, dt_obj)},
+                                     "before each worker's clock starts; rate = loci / the slowest worker's pass (%.2f s); one worker alone: %.1f loci/s"
+                                     % (n_obj, w_obj, per_w, dt_obj, n_one_o / dt_one_o)},
         "python_pool_chunked": {"value": n_ch / dt_ch, "unit": "loci/s", "cores": phys, "logical_cpus": cores, "kind": "port",
                                 "sample": "first %d loci, the same pool with 20 consecutive loci per task, every worker generating its own "
                                           "loci inside the clock (rounds 2-3's variant), %.1f s" % (n_ch, dt_ch)},
