@@ -254,6 +254,10 @@ def iter_resident_batches(path: str, fasta, loci: Sequence[Tuple[str, str]], par
                 if done is None:
                     # host builder (the run is not one the device path takes): same planes, uploaded
                     nl, hp, ustart, lc, tb = bam.planes_run(chrom, lo, hi, max_reads - total, params, run_ref, nthreads, fasta)
+                    if sampler == "philox" and params.ds > 0 and bool((lc["n_umi"] > params.ds).any()):
+                        import warnings
+                        warnings.warn("--sampler philox: the run %s:%d-%d was built on the host (not one the device builder takes): its loci "
+                                      "over the UMI cap keep the reference's sample" % (chrom, lo + 1, lo + nl))
                     ns = len(hp[0])
                     if slots + ns > cap or umi_base + len(ustart) > cap + 8192:
                         raise bamio.BamError("run of %d read slots does not fit the device arena" % ns)
