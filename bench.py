@@ -53,7 +53,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps each; value = the median block")
+    ap.add_argument("--blocks", type=int, default=25, help="timed blocks of EXACTLY --steps steps each (barrier + synchronize on both sides of "
+                                                           "every block); value = the median block.  25 blocks of 20 steps are 1.3 s of device work: a median "
+                                                           "over more blocks, and long enough for an outside observer of the GPU to see it busy")
     ap.add_argument("--place", type=int, default=0,
                     help="(round 4's bench-side trials, kept for comparison) extra allocations of the read words tried by the BENCH at "
                          "set-up, each timed with the real walk, the fastest kept.  Default 0: the library places the array itself - "
@@ -529,7 +531,8 @@ def compact(out: dict) -> dict:
         if k in line["config"] and len(line["config"][k]) > 260:
             line["config"][k] = line["config"][k][:257] + "..."
     if "blocks" in out:
-        line["blocks_ms_per_step"] = out["blocks"]["ms_per_step"]
+        b = sorted(out["blocks"]["ms_per_step"])                 # (the sidecar lists every block)
+        line["blocks_ms_per_step"] = {"n": len(b), "min": b[0], "median": b[len(b) // 2], "max": b[-1]}
     rf = out.get("roofline")
     if rf is not None:
         line["roofline"] = _pick(rf, ("bound", "kernel", "kernel_ms", "kernel_samples", "needed_bytes_per_launch", "achieved", "peak",
