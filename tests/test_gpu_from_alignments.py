@@ -295,3 +295,36 @@ def test_filter_tallies_by_their_own_kernel_give_the_same_rows(engine0, monkeypa
         assert out["0"].tobytes() == out["1"].tobytes() == dflt.tobytes()
         flt = (dflt["cand"]["flt_applied"] != 0).any(axis=1)
         assert int(flt.sum()) >= nl // 8 and int(dflt["ref_tal"][flt][:, 1:9].sum()) > 0
+
+
+def test_plans_without_the_host_on_loci_of_the_deep_class(engine0):
+    """smc_plan_create_dev_spec with loci of the deep class (several workgroups per locus, parts cut on the device by
+    k_plan_deep_spec from the record k_plan_classify left, the accumulators and flag scratch sized from the last plan's record): the
+    rows of a second and third run of example-depth loci - made without the host - are byte for byte those of the plan made the
+    exact way, the device counted no misfit, and a run twice as long fits the scaled sizes."""
+    from smcounter_amd import devplanes
+    from smcounter_amd.engine import Engine
+    eng = Engine(0)
+    try:
+        cfg = synth.CONFIGS["EX"]
+        P = synth.params_for(cfg)
+        outs = []
+        for n in (60, 60, 120):
+            A = synth.generate_alignments(cfg, n, P)
+            rb = devplanes.resident_from_alignments(A, eng, P, all_planes=False)
+            d_loci = devplanes.DevLoci(eng, rb.loci)
+            exact = eng.make_plan_dev(d_loci, rb.n_loci)
+            want = exact.run_devbuf([rb.words, rb.planes[4]], P).copy()
+            exact.close()
+            plan = eng.make_plan_dev(d_loci, rb.n_loci, spec_params=P)
+            got = plan.run_devbuf([rb.words, rb.planes[4]], P).copy()
+            ok = plan.ok()
+            plan.close()
+            d_loci.free()
+            outs.append((ok, got.tobytes() == want.tobytes(), int(want["cvg"].max())))
+        assert outs[0][:2] == (True, True) and outs[1][:2] == (True, True) and outs[2][:2] == (True, True), outs
+        assert outs[0][2] > 24576                                   # (loci of the deep class were in it)
+        made, exact_n, misfit = eng.spec_counts()
+        assert (made, exact_n, misfit) == (2, 1, 0)
+    finally:
+        eng.close()
