@@ -13,6 +13,7 @@ first, n = int(sys.argv[1]), int(sys.argv[2])
 eng = engine.Engine(0)
 cores = min(64, len(os.sched_getaffinity(0)))
 bad_total = 0
+n_misfit = 0
 for seed in range(first, first + n):
     rng = np.random.RandomState(seed)
     kind = seed % 6
@@ -46,9 +47,29 @@ for seed in range(first, first + n):
         np.savez(os.environ["FA_SOAK_DUMP"].split(":")[1], words=rb.words.download(np.uint32, rb.n_slots),
                  ustart=rb.planes[4].download(np.uint32, rb.n_ustart), loci=rb.loci)
     d_loci = devplanes.DevLoci(eng, rb.loci)
-    plan = eng.make_plan_dev(d_loci, rb.n_loci)
+    # two seeds of three make their plan WITHOUT the host (smc_plan_create_dev_spec: sized from whatever shape came before - most do
+    # not fit, say so, and are made again the exact way; the ones that fit must give the same rows)
+    spec = P if seed % 3 else None
+    plan = eng.make_plan_dev(d_loci, rb.n_loci, spec_params=spec)
     got = plan.run_devbuf([rb.words, rb.planes[4]], P).copy()
-    plan.close(); d_loci.free()
+    if not plan.ok():
+        n_misfit += 1
+        plan.close()
+        plan = eng.make_plan_dev(d_loci, rb.n_loci, spec_params=spec)
+        got = plan.run_devbuf([rb.words, rb.planes[4]], P).copy()
+        assert plan.ok()
+    plan.close()
+    # ... and once more, sized from this very batch's record: it fits, and gives the same bytes
+    for attempt in range(2):                  # (sized from an earlier seed's batch it may not fit: then it says so and is made again)
+        plan = eng.make_plan_dev(d_loci, rb.n_loci, spec_params=P)
+        again = plan.run_devbuf([rb.words, rb.planes[4]], P).copy()
+        fits = plan.ok()
+        plan.close()
+        if fits:
+            break
+        n_misfit += 1
+    assert fits and again.tobytes() == got.tobytes(), "seed %d: the plan made without the host differs (fits: %s)" % (seed, fits)
+    d_loci.free()
     db = oracle_lib.aln_planes(A, P, 0, nl, n_threads=cores)
     want, fragile, pi_all = oracle_lib.call_batch_mt(db, abi.c_params(P), abi.ROW_DTYPE, cores, return_fragile=True, return_pi_all=True)
     problems = abi.compare_rows(got, want, 1e-6, 1e-6, fragile, pi_all)
@@ -61,4 +82,4 @@ for seed in range(first, first + n):
     if problems:
         bad_total += 1
         print("seed %d (%d barcodes x %d, %d loci, depth %.0f): %d problems, first: %s" % (seed, n_umi, rpb, nl, A["reads"] / nl, len(problems), problems[0]), flush=True)
-print("from-alignments soak: %d seeds, %d with problems" % (n, bad_total))
+print("from-alignments soak: %d seeds, %d with problems; plans without the host: %s, %d said they did not fit" % (n, bad_total, eng.spec_counts(), n_misfit))
