@@ -310,6 +310,45 @@ def test_cli_device_and_host_planes_write_the_same_files(tmp_path, monkeypatch):
     assert outs[0] == outs[1] and outs[0].count("\n") > 10
 
 
+def test_cli_sampler_option(tmp_path):
+    """`--sampler philox` through the command line: files that differ from the default's (the reference-exact sample) at the loci
+    over the UMI cap only, the same for every --batchReads (the sample does not depend on how the file is cut), another for another
+    --samplerSeed; the help text says that it is NOT smCounter's sample."""
+    import test_bamio
+    from smcounter_amd import cli
+    bam, fa_path, loci = test_bamio._random_bam(tmp_path, 23, True)
+    bed = str(tmp_path / "t.bed")
+    with open(bed, "w") as fh:                               # (the fixture's stretches of consecutive positions as BED intervals)
+        keep = [(c, int(p)) for c, p in loci if c in ("chrA", "chrB")]
+        start = prev = None
+        for c, p in keep + [(None, 0)]:
+            if start is not None and (c != start[0] or p != prev + 1):
+                fh.write("%s\t%d\t%d\n" % (start[0], start[1] - 1, prev))
+                start = None
+            if c is not None and start is None:
+                start = (c, p)
+            prev = p
+
+    def run(tag, **kw):
+        prefix = str(tmp_path / tag)
+        cli.main(dict(outPrefix=prefix, bamFile=bam, bedTarget=bed, mtDepth=4, rpb=3.0, hpLen=8, minBQ=15, minMQ=20, mismatchThr=8.0,
+                      refGenome=fa_path, **kw))
+        return open(prefix + ".smCounter.all.txt").read().splitlines()
+
+    ref = run("ref")
+    ph = run("ph", sampler="philox")
+    ph_cut = run("phcut", sampler="philox", batchReads=200)
+    ph_seed = run("phseed", sampler="philox", samplerSeed=9)
+    assert len(ref) == len(ph) > 20 and ph == ph_cut
+    differ = [i for i, (a, b) in enumerate(zip(ref, ph)) if a != b]
+    assert differ and len(differ) < len(ref) - 1
+    umt = ref[0].split("\t").index("UMT")
+    assert all(ref[i].split("\t")[umt] == ph[i].split("\t")[umt] == "8" for i in differ)      # usedMT = ds = 2 x mtDepth at exactly those loci
+    assert ph_seed != ph
+    help_text = " ".join(cli.build_parser().format_help().split())
+    assert "--sampler" in help_text and "NOT the reference's sample" in help_text
+
+
 @pytest.mark.parametrize("name,n_loci", [("C2", 900), ("C3", 260), ("X2", 130)])
 def test_synthetic_alignments_through_the_device_builder_and_through_the_decoder(engine0, tmp_path, name, n_loci):
     """bench.py's `from_alignments` input (synth.generate_alignments: the decoder's output format, made without a BAM) built
